@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- attention fw+bw throughput of the HIP path on MI355X, one JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one FlashAttention-2 forward + backward pass (fa_mi355x_fwd + fa_mi355x_bwd, device-pointer C ABI)
+over one synthetic batch that is already resident in HBM.  Workload at N=1: the shape BASELINE.json's metric is
+quoted on -- B=8, H=8, N=4096, d=64, bf16 inputs (fp32 outputs), non-causal.  With --gpus N every rank runs that
+same batch on its own GPU (batch*head shards are independent: weak scaling, no data-path collective in the timed
+region); the one RCCL all-gather of O the north star describes is timed separately and reported as
+``gather_ms`` (never inside ``value``).
+
+FLOP accounting: fw = 4*B*H*N^2*d, bw = 10*B*H*N^2*d; softmax flops not counted.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel (longest average launch): algorithmic FLOPs per launch / HIP-event duration,
+                  against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline -- the oracle's NumPy fp32 vanilla attention fw+bw (oracle/attention_ref.py), timed on this host on a
+                  bounded sample of heads of the same workload (rank 0, --gpus 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--seqlen", type=int, default=4096)
+    ap.add_argument("--headdim", type=int, default=64)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--causal", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-heads", type=int, default=8, help="heads of the workload the CPU baseline runs")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from flash_attention_minitorch_amd import device_ops
+
+    B, H, N, d = args.batch, args.heads, args.seqlen, args.headdim
+    BH = B * H
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    causal = bool(args.causal)
+    gen = torch.Generator(device="cuda").manual_seed(1004 + rank)
+    mk = lambda: ((torch.rand((BH, N, d), device="cuda", generator=gen) - 0.5) * 2).to(tdt)  # U(-1,1), test_utils.py:104
+    q, k, v, do = mk(), mk(), mk(), mk()
+    out = torch.empty((BH, N, d), dtype=torch.float32, device="cuda")
+    L = torch.empty((BH, N), dtype=torch.float32, device="cuda")
+    grads = tuple(torch.empty((BH, N, d), dtype=torch.float32, device="cuda") for _ in range(3))
+    ws = device_ops.bwd_workspace(q)
+
+    def fwd():
+        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L)
+
+    def bwd(stages=device_ops.STAGE_ALL):
+        device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages)
+
+    def step():
+        fwd()
+        bwd()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cf = 0.5 if causal else 1.0
+    flops_fw = 4.0 * BH * N * N * d * cf
+    flops_bw = 10.0 * BH * N * N * d * cf
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * (flops_fw + flops_bw) / (elapsed / args.steps) / 1e12
+
+    # ---- per-kernel durations with HIP events on the launch stream (torch's current stream) ----------
+    def time_ms(fn, iters=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    kernels = {}
+    roofline = None
+    if not args.no_kernel_breakdown:
+        kernels = {
+            "fwd_kernel": (time_ms(fwd), flops_fw),
+            "bwd_prep_kernel": (time_ms(lambda: bwd(device_ops.STAGE_PREP)), 0.0),
+            "bwd_dkdv_kernel": (time_ms(lambda: bwd(device_ops.STAGE_DKDV)), 8.0 * BH * N * N * d * cf),
+            "bwd_dq_kernel": (time_ms(lambda: bwd(device_ops.STAGE_DQ)), 2.0 * BH * N * N * d * cf),
+        }
+        # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
+        # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
+        dom = max(kernels, key=lambda n: kernels[n][0])
+        dur_ms, fl = kernels[dom]
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        achieved = fl / (dur_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "avg_launch_ms": round(dur_ms, 4), "flops_per_launch": fl}
+
+    gather_ms = None
+    if world > 1:
+        from flash_attention_minitorch_amd import sharded
+        sharded.all_gather_bh(out, BH * world)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            sharded.all_gather_bh(out, BH * world)
+        barrier()
+        gather_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        import oracle
+        nh = max(1, min(args.cpu_heads, BH))
+        hq, hk, hv, hdo = (t[:nh].float().cpu().numpy() for t in (q, k, v, do))
+        oracle.vanilla_attention_fw_bw_f32(hq[:1, :256], hk[:1, :256], hv[:1, :256], hdo[:1, :256], causal)  # warm BLAS
+        c0 = time.perf_counter()
+        for hh in range(nh):
+            oracle.vanilla_attention_fw_bw_f32(hq[hh], hk[hh], hv[hh], hdo[hh], causal)
+        ct = time.perf_counter() - c0
+        cpu_flops = 14.0 * nh * N * N * d * cf
+        cpu_baseline = {"value": round(cpu_flops / ct / 1e12, 5), "unit": "TFLOP/s", "cores": os.cpu_count(),
+                        "kind": "port",
+                        "sample": f"{nh} of {BH} heads of the same workload (NumPy fp32 materialised-S attention fw+bw, "
+                                  f"BLAS threads = all cores), {ct:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "attn fw+bw TFLOP/s at (B=8,H=8,N=4096,d=64); % MFMA roofline",
+            "value": round(value, 2),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"FlashAttention-2 fw+bw, B={B} H={H} N={N} d={d}, {args.dtype} in / fp32 out, "
+                                   f"{'causal' if causal else 'non-causal'}, per GPU",
+                       "B": B, "H": H, "N": N, "d": d, "causal": causal,
+                       "parallelism": f"batch*head shard x{world}" if world > 1 else "single GPU"},
+            "pct_mfma_roofline": round(100.0 * value / world / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 2),
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

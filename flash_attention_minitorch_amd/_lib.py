@@ -1,0 +1,96 @@
+"""ctypes loader for the HIP libraries built by ``compile_cuda.sh``.
+
+Mirrors the six ``ctypes.CDLL`` handles of the reference (``minitorch/cuda_kernel_ops.py:30-35``), but with
+paths resolved relative to this package instead of the current directory, and lazily, so importing the
+package on a machine without the build (or without a GPU) does not fail until an op is called.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+try:  # torch first: its bundled HIP runtime must be the one (and only) libamdhip64 in the process,
+    import torch  # noqa: F401  so torch stream handles / device pointers are valid in our launches.
+except Exception:  # pragma: no cover - torch-less host-array use
+    torch = None
+
+KERNEL_DIR = os.environ.get(
+    "FA_MI355X_KERNEL_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "cuda_kernels")
+)
+
+CORE_NAME = "libflash_attn_mi355x.so"
+VARIANT_LIBS = (
+    "flash_attn_fw.so",
+    "flash_attn_bw.so",
+    "flash_attn2_fw.so",
+    "flash_attn2_bw.so",
+    "flash_attn_causal_fw.so",
+    "flash_attn_causal_bw.so",
+)
+
+FA_VARIANT_FA1 = 1
+FA_VARIANT_FA2 = 2
+FA_DTYPE_F32 = 0
+FA_DTYPE_BF16 = 1
+FA_OK = 0
+
+_handles: dict = {}
+
+
+class FlashAttnLibraryError(RuntimeError):
+    pass
+
+
+def lib_path(name: str) -> str:
+    return os.path.join(KERNEL_DIR, name)
+
+
+def load(name: str) -> ctypes.CDLL:
+    """dlopen one of the built libraries; raises loudly when it is missing (no fallback path exists)."""
+    h = _handles.get(name)
+    if h is not None:
+        return h
+    path = lib_path(name)
+    if not os.path.exists(path):
+        raise FlashAttnLibraryError(
+            f"{path} not found: build the HIP libraries first (./compile_cuda.sh, or "
+            f"python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback."
+        )
+    try:
+        h = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL if name == CORE_NAME else ctypes.DEFAULT_MODE)
+    except OSError as e:  # e.g. libamdhip64.so missing
+        raise FlashAttnLibraryError(f"could not load {path}: {e}") from e
+    _handles[name] = h
+    return h
+
+
+_vp, _i, _fp = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
+
+
+def core() -> ctypes.CDLL:
+    """libflash_attn_mi355x.so with argtypes set for the device-pointer entry points."""
+    h = load(CORE_NAME)
+    if getattr(h, "_fa_typed", False):
+        return h
+    h.fa_mi355x_fwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    h.fa_mi355x_fwd.restype = _i
+    h.fa_mi355x_bwd.argtypes = [_vp] * 11 + [_i] * 6 + [_vp]
+    h.fa_mi355x_bwd.restype = _i
+    h.fa_mi355x_bwd_stages.argtypes = [_vp] * 11 + [_i] * 7 + [_vp]
+    h.fa_mi355x_bwd_stages.restype = _i
+    h.fa_mi355x_bwd_workspace_bytes.argtypes = [_i, _i, _i]
+    h.fa_mi355x_bwd_workspace_bytes.restype = ctypes.c_size_t
+    h.fa_mi355x_last_error.argtypes = []
+    h.fa_mi355x_last_error.restype = ctypes.c_char_p
+    h.fa_mi355x_version.argtypes = []
+    h.fa_mi355x_version.restype = ctypes.c_char_p
+    h.fa_mi355x_probe.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
+    h.fa_mi355x_probe.restype = _i
+    h._fa_typed = True
+    return h
+
+
+def check(status: int) -> None:
+    if status != FA_OK:
+        msg = core().fa_mi355x_last_error().decode()
+        raise FlashAttnLibraryError(f"flash_attn_mi355x error {status}: {msg}")

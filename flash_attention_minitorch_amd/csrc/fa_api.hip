@@ -1,0 +1,305 @@
+// C ABI of the MI355X FlashAttention library (declared in include/flash_attn_mi355x.h):
+// kernel dispatch for the device-pointer entry points and the host-pointer launchers that stand in
+// for the reference's launch_flash_attn_fw / launch_flash_attn_bw (src/flash_attn_fw.cu:300-359,
+// src/flash_attn_bw.cu:275-365, src/flash_attn2_fw.cu:310-372, src/flash_attn2_bw.cu:277-369).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/flash_attn_mi355x.h"
+#include "fa_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* what, hipError_t e = hipSuccess) {
+  if (e != hipSuccess)
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(g_err, sizeof(g_err), "%s", what);
+  return code;
+}
+
+#define FA_HIP_TRY(expr)                                           \
+  do {                                                             \
+    hipError_t e_ = (expr);                                        \
+    if (e_ != hipSuccess) return set_err(FA_ERR_HIP, #expr, e_);   \
+  } while (0)
+
+inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
+inline int d_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
+
+template <typename T, int D>
+int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
+               int causal, int variant, float tau, hipStream_t st) {
+  constexpr int BN = sizeof(T) == 2 ? 64 : 32;
+  const int nqb = (N + 127) / 128;
+  hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+                     (const T*)v, out, l, m, N, nqb, batch, causal, variant, tau);
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
+template <typename T, int D>
+int bwd_launch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
+               float* dv, const float* l, const float* m, float* ws, int batch, int N, int causal, int variant,
+               float tau, int stages, hipStream_t st) {
+  constexpr int BN = sizeof(T) == 2 ? 64 : 32;
+  constexpr int KPW = (sizeof(T) == 2 && D <= 64) ? 64 : 32;
+  const long rows = (long)batch * N;
+  float* nl = ws;
+  float* nd = ws + rows;
+  constexpr int RPB = 256 / (D / 8);
+  if (stages & FA_BWD_STAGE_PREP) {
+    hipLaunchKernelGGL((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
+                       (const T*)dout, l, m, nl, nd, rows, variant, 1.0f / tau);
+    FA_HIP_TRY(hipGetLastError());
+  }
+  if (stages & FA_BWD_STAGE_DKDV) {
+    const int nkb = (N + 4 * KPW - 1) / (4 * KPW);
+    hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW>), dim3(batch * nkb), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)v, (const T*)dout, nl, nd, dk, dv, N, nkb, batch, causal, tau);
+    FA_HIP_TRY(hipGetLastError());
+  }
+  if (stages & FA_BWD_STAGE_DQ) {
+    const int nqb = (N + 127) / 128;
+    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+                       (const T*)v, (const T*)dout, nl, nd, dq, N, nqb, batch, causal, tau);
+    FA_HIP_TRY(hipGetLastError());
+  }
+  return FA_OK;
+}
+
+#define FA_DISPATCH(FN, ...)                                                              \
+  do {                                                                                    \
+    if (dtype == FA_DTYPE_BF16) {                                                         \
+      if (dp == 32) return FN<fa::bf16_t, 32>(__VA_ARGS__);                               \
+      if (dp == 64) return FN<fa::bf16_t, 64>(__VA_ARGS__);                               \
+      return FN<fa::bf16_t, 128>(__VA_ARGS__);                                            \
+    } else {                                                                              \
+      if (dp == 32) return FN<float, 32>(__VA_ARGS__);                                    \
+      if (dp == 64) return FN<float, 64>(__VA_ARGS__);                                    \
+      return FN<float, 128>(__VA_ARGS__);                                                 \
+    }                                                                                     \
+  } while (0)
+
+// tau uses the caller's d even when the rows are zero-padded to dp columns (zero columns of Q/K add
+// nothing to the scores; zero columns of V produce zero output columns that are dropped).
+int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
+                 int dp, int causal, int variant, int dtype, hipStream_t st) {
+  const float tau = sqrtf(1.0f / (float)d);
+  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, causal, variant, tau, st);
+}
+
+int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
+                 float* dv, const float* l, const float* m, float* ws, int batch, int N, int d, int dp, int causal,
+                 int variant, int dtype, int stages, hipStream_t st) {
+  const float tau = sqrtf(1.0f / (float)d);
+  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, causal, variant, tau, stages, st);
+}
+
+int check_common(int batch, int N, int d, int variant, int dtype) {
+  if (batch <= 0 || N <= 0 || d <= 0) return set_err(FA_ERR_BAD_ARG, "batch, N and d must be positive");
+  if (variant != FA_VARIANT_FA1 && variant != FA_VARIANT_FA2) return set_err(FA_ERR_BAD_ARG, "unknown variant");
+  if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return set_err(FA_ERR_BAD_ARG, "unknown dtype");
+  if ((long)batch * N * d >= (1L << 40)) return set_err(FA_ERR_BAD_ARG, "tensor too large");
+  return FA_OK;
+}
+
+// ---- host-pointer path ------------------------------------------------------------------------
+// A grow-only device arena replaces the reference's per-call cudaMalloc/cudaFree of 6 (fw) or 10 (bw)
+// buffers (src/flash_attn_fw.cu:315-322,352-357).
+std::mutex g_pool_mu;
+void* g_pool = nullptr;
+size_t g_pool_bytes = 0;
+
+hipError_t pool_reserve(size_t bytes) {
+  if (bytes <= g_pool_bytes) return hipSuccess;
+  if (g_pool) {
+    hipError_t e = hipFree(g_pool);
+    g_pool = nullptr;
+    g_pool_bytes = 0;
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipMalloc(&g_pool, bytes);
+  if (e == hipSuccess) g_pool_bytes = bytes;
+  return e;
+}
+
+[[noreturn]] void die(const char* what, hipError_t e) {
+  // src/flash_attn_fw.cu:343-349: message on stderr, exit(EXIT_FAILURE)
+  fprintf(stderr, "Flash Attention Error: %s%s%s\n", what, e != hipSuccess ? ": " : "",
+          e != hipSuccess ? hipGetErrorString(e) : "");
+  exit(EXIT_FAILURE);
+}
+#define FA_HOST_TRY(expr)                        \
+  do {                                           \
+    hipError_t e_ = (expr);                      \
+    if (e_ != hipSuccess) die(#expr, e_);        \
+  } while (0)
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// host [rows][d] -> device [rows][dp] (zero padded columns)
+void h2d_rows(float* dst, const float* src, size_t rows, int d, int dp, hipStream_t st) {
+  if (d == dp) {
+    FA_HOST_TRY(hipMemcpyAsync(dst, src, rows * d * sizeof(float), hipMemcpyHostToDevice, st));
+  } else {
+    FA_HOST_TRY(hipMemsetAsync(dst, 0, rows * dp * sizeof(float), st));
+    FA_HOST_TRY(hipMemcpy2DAsync(dst, dp * sizeof(float), src, d * sizeof(float), d * sizeof(float), rows,
+                                 hipMemcpyHostToDevice, st));
+  }
+}
+void d2h_rows(float* dst, const float* src, size_t rows, int d, int dp, hipStream_t st) {
+  if (d == dp) {
+    FA_HOST_TRY(hipMemcpyAsync(dst, src, rows * d * sizeof(float), hipMemcpyDeviceToHost, st));
+  } else {
+    FA_HOST_TRY(hipMemcpy2DAsync(dst, d * sizeof(float), src, dp * sizeof(float), d * sizeof(float), rows,
+                                 hipMemcpyDeviceToHost, st));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fa_mi355x_last_error(void) { return g_err; }
+const char* fa_mi355x_version(void) { return "flash_attn_mi355x 0.1 gfx950"; }
+
+int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
+                  int d, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  return fwd_dispatch(q, k, v, out, l, m, batch, N, d, d, causal ? 1 : 0, variant, dtype, (hipStream_t)stream);
+}
+
+size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d) {
+  (void)d;
+  if (batch <= 0 || N <= 0) return 0;
+  return (size_t)2 * batch * N * sizeof(float);
+}
+
+int fa_mi355x_bwd(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                  float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N,
+                  int d, int causal, int variant, int dtype, void* stream) {
+  return fa_mi355x_bwd_stages(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, workspace, batch, N, d, causal,
+                              variant, dtype, FA_BWD_STAGE_ALL, stream);
+}
+
+int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                         float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m, void* workspace,
+                         int batch, int N, int d, int causal, int variant, int dtype, int stages, void* stream) {
+  g_err[0] = 0;
+  if (stages <= 0 || stages > FA_BWD_STAGE_ALL) return set_err(FA_ERR_BAD_ARG, "bad stages mask");
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, batch, N, d, d,
+                      causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream);
+}
+
+void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* out, float* l, float* m, int batch,
+                              int N, int d, bool causal_mask, void* stream) {
+  if (!q || !k || !v || !out || !l || !m) die("null pointer argument", hipSuccess);
+  if (batch <= 0 || N <= 0 || d <= 0) die("batch, N and d must be positive", hipSuccess);
+  // The reference kernels assert d <= 128 (FA-1, src/flash_attn_fw.cu:43) / d <= 126 (FA-2, src/flash_attn2_fw.cu:43).
+  if (d > 128) die("head dimension d > 128 is not supported", hipSuccess);
+  hipStream_t st = (hipStream_t)stream;
+  const int dp = d_padded(d);
+  const size_t rows = (size_t)batch * N;
+  const size_t tb = align256(rows * dp * sizeof(float)), rb = align256(rows * sizeof(float));
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  FA_HOST_TRY(pool_reserve(4 * tb + 2 * rb));
+  char* p = (char*)g_pool;
+  float* dq_ = (float*)p;
+  float* dk_ = (float*)(p + tb);
+  float* dv_ = (float*)(p + 2 * tb);
+  float* do_ = (float*)(p + 3 * tb);
+  float* dl_ = (float*)(p + 4 * tb);
+  float* dm_ = (float*)(p + 4 * tb + rb);
+  h2d_rows(dq_, q, rows, d, dp, st);
+  h2d_rows(dk_, k, rows, d, dp, st);
+  h2d_rows(dv_, v, rows, d, dp, st);
+  if (fwd_dispatch(dq_, dk_, dv_, do_, dl_, dm_, batch, N, d, dp, causal_mask ? 1 : 0, variant, FA_DTYPE_F32, st))
+    die(g_err, hipSuccess);
+  d2h_rows(out, do_, rows, d, dp, st);
+  FA_HOST_TRY(hipMemcpyAsync(l, dl_, rows * sizeof(float), hipMemcpyDeviceToHost, st));
+  // FA-2 never writes m (src/flash_attn2_fw.cu:279-294): the caller's m comes back unchanged.
+  if (variant == FA_VARIANT_FA1) FA_HOST_TRY(hipMemcpyAsync(m, dm_, rows * sizeof(float), hipMemcpyDeviceToHost, st));
+  FA_HOST_TRY(hipStreamSynchronize(st));
+  FA_HOST_TRY(hipGetLastError());
+}
+
+void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* out, float* out_grad, float* q_grad,
+                              float* k_grad, float* v_grad, float* l, float* m, int batch, int N, int d,
+                              bool causal_mask, void* stream) {
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !m)
+    die("null pointer argument", hipSuccess);
+  if (batch <= 0 || N <= 0 || d <= 0) die("batch, N and d must be positive", hipSuccess);
+  if (d > 128) die("head dimension d > 128 is not supported", hipSuccess);
+  hipStream_t st = (hipStream_t)stream;
+  const int dp = d_padded(d);
+  const size_t rows = (size_t)batch * N;
+  const size_t tb = align256(rows * dp * sizeof(float)), rb = align256(rows * sizeof(float));
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  FA_HOST_TRY(pool_reserve(8 * tb + 4 * rb));
+  char* p = (char*)g_pool;
+  float* bq = (float*)p;
+  float* bk = (float*)(p + tb);
+  float* bv = (float*)(p + 2 * tb);
+  float* bo = (float*)(p + 3 * tb);
+  float* bdo = (float*)(p + 4 * tb);
+  float* bdq = (float*)(p + 5 * tb);
+  float* bdk = (float*)(p + 6 * tb);
+  float* bdv = (float*)(p + 7 * tb);
+  float* bl = (float*)(p + 8 * tb);
+  float* bm = (float*)(p + 8 * tb + rb);
+  float* ws = (float*)(p + 8 * tb + 2 * rb);
+  h2d_rows(bq, q, rows, d, dp, st);
+  h2d_rows(bk, k, rows, d, dp, st);
+  h2d_rows(bv, v, rows, d, dp, st);
+  h2d_rows(bo, out, rows, d, dp, st);
+  h2d_rows(bdo, out_grad, rows, d, dp, st);
+  FA_HOST_TRY(hipMemcpyAsync(bl, l, rows * sizeof(float), hipMemcpyHostToDevice, st));
+  FA_HOST_TRY(hipMemcpyAsync(bm, m, rows * sizeof(float), hipMemcpyHostToDevice, st));
+  if (bwd_dispatch(bq, bk, bv, bo, bdo, bdq, bdk, bdv, bl, bm, ws, batch, N, d, dp, causal_mask ? 1 : 0, variant,
+                   FA_DTYPE_F32, FA_BWD_STAGE_ALL, st))
+    die(g_err, hipSuccess);
+  d2h_rows(q_grad, bdq, rows, d, dp, st);
+  d2h_rows(k_grad, bdk, rows, d, dp, st);
+  d2h_rows(v_grad, bdv, rows, d, dp, st);
+  FA_HOST_TRY(hipStreamSynchronize(st));
+  FA_HOST_TRY(hipGetLastError());
+}
+
+int fa_mi355x_probe(const void* tile, const void* b, float* row_out, float* tr_out, float* mma_out, float* swap_out,
+                    int d, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (!tile || !b || !row_out || !tr_out || !mma_out || !swap_out) return set_err(FA_ERR_BAD_ARG, "null pointer");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "probe supports d in {32, 64, 128}");
+  hipStream_t st = (hipStream_t)stream;
+#define FA_PROBE(T, DD)                                                                                      \
+  hipLaunchKernelGGL((fa::probe_kernel<T, DD>), dim3(1), dim3(64), 0, st, (const T*)tile, (const T*)b, row_out, \
+                     tr_out, mma_out, swap_out)
+  if (dtype == FA_DTYPE_BF16) {
+    if (d == 32) FA_PROBE(fa::bf16_t, 32); else if (d == 64) FA_PROBE(fa::bf16_t, 64); else FA_PROBE(fa::bf16_t, 128);
+  } else if (dtype == FA_DTYPE_F32) {
+    if (d == 32) FA_PROBE(float, 32); else if (d == 64) FA_PROBE(float, 64); else FA_PROBE(float, 128);
+  } else {
+    return set_err(FA_ERR_BAD_ARG, "unknown dtype");
+  }
+#undef FA_PROBE
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
+}  // extern "C"

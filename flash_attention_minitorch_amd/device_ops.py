@@ -1,0 +1,121 @@
+"""Device-resident entry points: torch-ROCm tensors in, torch-ROCm tensors out, no host round trip.
+
+This is SURVEY.md row f2 (replace the reference's per-call malloc / H2D / D2H,
+``src/flash_attn_fw.cu:314-357``, with persistent device tensors) and what ``bench.py`` times.
+torch is plumbing only: device memory, streams.  All arithmetic runs in the HIP kernels.
+
+Tensors are (B, H, N, d) or (BH, N, d), contiguous, float32 or bfloat16; outputs (O, dQ, dK, dV) are
+float32 (a bf16 store alone would exceed the 1e-3 max-abs bound).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.FA_DTYPE_F32, torch.bfloat16: _lib.FA_DTYPE_BF16}
+
+
+def _check_inputs(*ts):
+    t0 = ts[0]
+    if not t0.is_cuda:
+        raise _lib.FlashAttnLibraryError("device_ops needs GPU tensors; there is no CPU fallback")
+    if t0.dtype not in _DTYPES:
+        raise TypeError(f"unsupported dtype {t0.dtype}: use float32 or bfloat16")
+    for t in ts:
+        if t.shape != t0.shape or t.dtype != t0.dtype or t.device != t0.device:
+            raise ValueError("q, k, v (and out_grad) must share shape, dtype and device")
+        if not t.is_contiguous():
+            raise ValueError("tensors must be contiguous [.., N, d]")
+    if t0.dim() not in (3, 4):
+        raise ValueError("expected (B, H, N, d) or (BH, N, d)")
+    n, d = t0.shape[-2], t0.shape[-1]
+    bh = t0.numel() // (n * d)
+    return bh, n, d
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None):
+    """Forward.  Returns (out fp32, l, m): FA-1 -> l = sum exp(s - rowmax), m = rowmax;
+    FA-2 -> l = logsumexp, m = None."""
+    bh, n, d = _check_inputs(q, k, v)
+    lead = q.shape[:-2]
+    if out is None:
+        out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    if l is None:
+        l = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
+    if variant == _lib.FA_VARIANT_FA1 and m is None:
+        m = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.core().fa_mi355x_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), bh, n, d,
+                                         int(bool(causal)), variant, _DTYPES[q.dtype], _stream_ptr()))
+    return out, l, m
+
+
+def bwd_workspace(q):
+    n, d = q.shape[-2], q.shape[-1]
+    bh = q.numel() // (n * d)
+    nbytes = _lib.core().fa_mi355x_bwd_workspace_bytes(bh, n, d)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+
+
+STAGE_PREP, STAGE_DKDV, STAGE_DQ, STAGE_ALL = 1, 2, 4, 7
+
+
+def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2,
+                   workspace=None, grads=None, stages=STAGE_ALL):
+    """Backward.  out: the forward's fp32 output.  Returns (dq, dk, dv) fp32.
+    ``stages`` restricts the call to some of its kernels (profiling only)."""
+    bh, n, d = _check_inputs(q, k, v, out_grad)
+    if out.dtype != torch.float32 or out.shape != q.shape or not out.is_contiguous():
+        raise ValueError("out must be the forward's contiguous float32 output")
+    if workspace is None:
+        workspace = bwd_workspace(q)
+    if grads is None:
+        grads = tuple(torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
+    dq, dk, dv = grads
+    _lib.check(_lib.core().fa_mi355x_bwd_stages(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
+                                                _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(workspace), bh, n, d,
+                                                int(bool(causal)), variant, _DTYPES[q.dtype], int(stages),
+                                                _stream_ptr()))
+    return dq, dk, dv
+
+
+class _FlashAttnFn(torch.autograd.Function):
+    """Autograd contract of the reference's Flash_Attn / Flash_Attn2 / Flash_Attn_Causal
+    (minitorch/tensor_functions.py:462-497): forward returns o and saves (q, k, v, o, l, m, causal);
+    backward hands them to the SAME variant's backward.  Gradients are cast to the input dtype."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal, variant):
+        o, l, m = flash_attn_fwd(q, k, v, causal, variant)
+        ctx.save_for_backward(q, k, v, o, l, m if m is not None else torch.empty(0, device=q.device))
+        ctx.causal, ctx.variant = causal, variant
+        return o
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        q, k, v, o, l, m = ctx.saved_tensors
+        dq, dk, dv = flash_attn_bwd(q, k, v, o, out_grad.to(q.dtype).contiguous(), l,
+                                    m if m.numel() else None, ctx.causal, ctx.variant)
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None
+
+
+def flash_attn(q, k, v, causal=False):        # Tensor.flash_attn, minitorch/tensor.py:422-423
+    return _FlashAttnFn.apply(q, k, v, bool(causal), _lib.FA_VARIANT_FA1)
+
+
+def flash_attn_causal(q, k, v, causal=True):  # Tensor.flash_attn_causal, minitorch/tensor.py:425-426
+    return _FlashAttnFn.apply(q, k, v, bool(causal), _lib.FA_VARIANT_FA1)
+
+
+def flash_attn2(q, k, v, causal=False):       # Tensor.flash_attn2, minitorch/tensor.py:428-429
+    return _FlashAttnFn.apply(q, k, v, bool(causal), _lib.FA_VARIANT_FA2)

@@ -1,0 +1,90 @@
+"""Batch*head sharding of the attention path across the GPUs of one node.
+
+Every (batch, head) pair is independent in forward and backward (the reference kernels index by
+``blockIdx.x = batch*head`` only, ``src/flash_attn_fw.cu:25-35``), so the flattened BH axis is cut into
+contiguous slices, one per rank (one process per GPU), and the only communication is ONE all-gather of the
+outputs -- never a reduction.  ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI inside a node);
+the same code runs on "gloo" for the CPU tests.
+
+The reference has no counterpart (no distributed code of any kind).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(bh_total: int, world: int) -> Sequence[Tuple[int, int]]:
+    """Contiguous, balanced [begin, end) slices of the BH axis; the first (bh_total % world) ranks get one extra."""
+    if bh_total < 0 or world <= 0:
+        raise ValueError("bh_total >= 0 and world > 0 required")
+    base, extra = divmod(bh_total, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < extra else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+def shard_range(bh_total: int, rank: int, world: int) -> Tuple[int, int]:
+    return shard_bounds(bh_total, world)[rank]
+
+
+def all_gather_bh(local: torch.Tensor, bh_total: int, group=None) -> torch.Tensor:
+    """Gather rank-local [bh_local, ...] slices into the full [bh_total, ...] tensor on every rank (one collective)."""
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(bh_total, world)
+    sizes = [e - b for b, e in bounds]
+    if local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError(f"local slice has {local.shape[0]} rows, expected {sizes[dist.get_rank(group)]}")
+    local = local.contiguous()
+    if len(set(sizes)) == 1:
+        out = torch.empty((bh_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    # ragged split: pad every slice to the largest, gather once, drop the padding
+    mx = max(sizes)
+    padded = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+def _default_fwd(q, k, v, causal):
+    from . import device_ops, _lib
+    o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal, _lib.FA_VARIANT_FA2)
+    return o, L
+
+
+def _default_bwd(q, k, v, o, do, L, causal):
+    from . import device_ops, _lib
+    return device_ops.flash_attn_bwd(q, k, v, o, do, L, None, causal, _lib.FA_VARIANT_FA2)
+
+
+def sharded_flash_attn2_fwd(q_local, k_local, v_local, bh_total: int, causal: bool = False, gather: bool = True,
+                            group=None, compute_fn: Optional[Callable] = None):
+    """FA-2 forward on this rank's [bh_local, N, d] slice; returns (O, L) gathered over BH when ``gather``.
+
+    ``compute_fn(q, k, v, causal) -> (o, L)`` defaults to the HIP kernels; the CPU (gloo) tests inject a checker.
+    """
+    fn = compute_fn or _default_fwd
+    o, L = fn(q_local, k_local, v_local, causal)
+    if not gather:
+        return o, L
+    return all_gather_bh(o, bh_total, group), all_gather_bh(L, bh_total, group)
+
+
+def sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_local, bh_total: int,
+                            causal: bool = False, gather: bool = True, group=None,
+                            compute_fn: Optional[Callable] = None):
+    """FA-2 backward on this rank's slice; gradients of different (b, h) never overlap, so gathering them is
+    again an all-gather, not an all-reduce."""
+    fn = compute_fn or _default_bwd
+    dq, dk, dv = fn(q_local, k_local, v_local, o_local, do_local, L_local, causal)
+    if not gather:
+        return dq, dk, dv
+    return tuple(all_gather_bh(g, bh_total, group) for g in (dq, dk, dv))

@@ -1,0 +1,114 @@
+/*
+ * flash_attn_mi355x.h -- C ABI of the MI355X (gfx950) FlashAttention forward/backward library.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) The reference's own FFI, unchanged.  Each of the six shared objects the reference opens with
+ *      ctypes.CDLL at import time (minitorch/cuda_kernel_ops.py:30-35)
+ *          flash_attn_fw.so        flash_attn_bw.so          FA-1            (Makefile:28-34)
+ *          flash_attn_causal_fw.so flash_attn_causal_bw.so   FA-1 + causal block skipping (Makefile:36-42)
+ *          flash_attn2_fw.so       flash_attn2_bw.so         FA-2            (Makefile:44-50)
+ *      exports ONE unmangled symbol, launch_flash_attn_fw or launch_flash_attn_bw, with the reference's
+ *      signature (src/flash_attn_fw.cu:300-312, src/flash_attn_bw.cu:275-291; identical in the FA-2
+ *      files src/flash_attn2_fw.cu:310-322, src/flash_attn2_bw.cu:277-293).  Host fp32 pointers,
+ *      synchronous, no return code, message on stderr + exit(EXIT_FAILURE) on a GPU error
+ *      (src/flash_attn_fw.cu:343-349).  The shims forward to fa_mi355x_launch_fw_host / _bw_host below.
+ *
+ *  (2) Additive device-pointer entry points (libflash_attn_mi355x.so): asynchronous on the caller's
+ *      stream, int status, no allocation inside the call.  These are what bench.py times and what the
+ *      multi-GPU shard uses; the reference has no counterpart (its launchers malloc/copy/free per call,
+ *      src/flash_attn_fw.cu:314-357).
+ *
+ * Layout everywhere: row-major contiguous [batch][N][d] for q, k, v, out, out_grad, q_grad, k_grad,
+ * v_grad and [batch][N] for l, m, where batch = B*H (minitorch/cuda_kernel_ops.py:542-547,570).
+ */
+#ifndef FLASH_ATTN_MI355X_H
+#define FLASH_ATTN_MI355X_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) reference FFI: one of each per variant library ------------------------------------ */
+
+/* Replaces launch_flash_attn_fw of src/flash_attn_fw.cu:302-312 (FA-1; l = sum exp(s-m), m = row max)
+ * and of src/flash_attn2_fw.cu:312-322 (FA-2; l = logsumexp, m left as passed in).
+ * q,k,v,out: host float[batch*N*d]; l,m: host float[batch*N].  The caller pre-initialises out=0, l=0,
+ * m=-FLT_MAX (minitorch/cuda_kernel_ops.py:537-539); the values are not read.  stream: hipStream_t
+ * (torch.cuda.current_stream().cuda_stream on PyTorch-ROCm) or NULL. */
+void launch_flash_attn_fw(float* q, float* k, float* v, float* out, float* l, float* m,
+                          int batch, int N, int d, bool causal_mask, void* stream);
+
+/* Replaces launch_flash_attn_bw of src/flash_attn_bw.cu:277-291 / src/flash_attn2_bw.cu:279-293.
+ * q_grad, k_grad, v_grad are overwritten (the caller passes zeros, minitorch/cuda_kernel_ops.py:609-611).
+ * l, m: the side outputs of the SAME variant's forward (minitorch/tensor_functions.py:462-497). */
+void launch_flash_attn_bw(float* q, float* k, float* v, float* out, float* out_grad,
+                          float* q_grad, float* k_grad, float* v_grad, float* l, float* m,
+                          int batch, int N, int d, bool causal_mask, void* stream);
+
+/* ---- (2) core library ------------------------------------------------------------------------ */
+
+/* Side-output convention of a variant library. */
+#define FA_VARIANT_FA1 1        /* flash_attn_{fw,bw}.so, flash_attn_causal_{fw,bw}.so */
+#define FA_VARIANT_FA2 2        /* flash_attn2_{fw,bw}.so */
+
+/* Element type of q, k, v, out_grad on the device-pointer path (outputs are always fp32). */
+#define FA_DTYPE_F32  0         /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+#define FA_DTYPE_BF16 1         /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate / softmax state */
+
+/* Status codes of the int-returning entry points. */
+#define FA_OK 0
+#define FA_ERR_BAD_ARG 1        /* null pointer, non-positive size, unknown variant/dtype */
+#define FA_ERR_UNSUPPORTED_D 2  /* device path needs d in {32, 64, 128}; the host path pads any d <= 128 */
+#define FA_ERR_HIP 3            /* a HIP call failed: see fa_mi355x_last_error() */
+
+/* Host-pointer launchers behind the six shims (same argument meaning as the reference FFI + variant). */
+void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* out, float* l, float* m,
+                              int batch, int N, int d, bool causal_mask, void* stream);
+void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* out, float* out_grad,
+                              float* q_grad, float* k_grad, float* v_grad, float* l, float* m,
+                              int batch, int N, int d, bool causal_mask, void* stream);
+
+/* Forward on device pointers.  q,k,v: dtype elements [batch][N][d]; out: float [batch][N][d];
+ * l, m: float [batch][N] (m may be NULL for FA_VARIANT_FA2).  Asynchronous on `stream`. */
+int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m,
+                  int batch, int N, int d, int causal, int variant, int dtype, void* stream);
+
+/* Bytes of scratch fa_mi355x_bwd needs (2 * batch * N floats: -L/tau and -rowsum(dO*O)). */
+size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
+
+/* Backward on device pointers.  out: float (the forward's output); out_grad: dtype elements;
+ * q_grad,k_grad,v_grad: float, overwritten; workspace: device scratch of the size above. */
+int fa_mi355x_bwd(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                  float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
+                  void* workspace, int batch, int N, int d, int causal, int variant, int dtype, void* stream);
+
+/* The same, restricted to some of its three kernels (bench.py times them one by one; stages run in the order
+ * prep -> dK/dV -> dQ and the later two need prep's workspace contents). */
+#define FA_BWD_STAGE_PREP 1     /* workspace <- -L/tau, -rowsum(dO*O) */
+#define FA_BWD_STAGE_DKDV 2     /* k_grad, v_grad */
+#define FA_BWD_STAGE_DQ   4     /* q_grad */
+#define FA_BWD_STAGE_ALL  7
+int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                         float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
+                         void* workspace, int batch, int N, int d, int causal, int variant, int dtype, int stages,
+                         void* stream);
+
+/* Message of the last FA_ERR_* on this thread ("" if none). */
+const char* fa_mi355x_last_error(void);
+
+/* Library version, e.g. "flash_attn_mi355x 0.1 gfx950". */
+const char* fa_mi355x_version(void);
+
+/* Test hook: dumps what the MFMA operand readers see for a [64][d] tile (tests/test_gpu_layout.py).
+ * All pointers are device pointers; returns a status code. */
+int fa_mi355x_probe(const void* tile, const void* b, float* row_out, float* tr_out, float* mma_out,
+                    float* swap_out, int d, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASH_ATTN_MI355X_H */
