@@ -44,31 +44,48 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
   return FA_OK;
 }
 
+int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0]: dK/dV geometry (0 = default, 1 = 4 waves x 64 keys, 2 = 8 waves x 32 keys)
+
+template <typename T, int D, int KPW, int NW>
+int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
+                float* dk, float* dv, int batch, int N, int causal, float tau, hipStream_t st) {
+  const int nkb = (N + NW * KPW - 1) / (NW * KPW);
+  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
+                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, causal, tau);
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
 template <typename T, int D>
 int bwd_launch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
                float* dv, const float* l, const float* m, float* ws, int batch, int N, int causal, int variant,
                float tau, int stages, hipStream_t st) {
   constexpr int BN = sizeof(T) == 2 ? 64 : 32;
-  constexpr int KPW = (sizeof(T) == 2 && D <= 64) ? 64 : 32;
   const long rows = (long)batch * N;
-  float* nl = ws;
-  float* nd = ws + rows;
+  float* nlc = ws;
+  float* delta = ws + rows;
   constexpr int RPB = 256 / (D / 8);
   if (stages & FA_BWD_STAGE_PREP) {
     hipLaunchKernelGGL((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
-                       (const T*)dout, l, m, nl, nd, rows, variant, 1.0f / tau);
+                       (const T*)dout, l, m, nlc, delta, rows, variant);
     FA_HIP_TRY(hipGetLastError());
   }
   if (stages & FA_BWD_STAGE_DKDV) {
-    const int nkb = (N + 4 * KPW - 1) / (4 * KPW);
-    hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW>), dim3(batch * nkb), dim3(256), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, (const T*)dout, nl, nd, dk, dv, N, nkb, batch, causal, tau);
-    FA_HIP_TRY(hipGetLastError());
+    int rc;
+    if constexpr (sizeof(T) == 2 && D <= 64) {
+      if (g_tuning[0] == 1)
+        rc = dkdv_launch<T, D, 64, 4>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      else  // measured on MI355X at B=8,H=8,N=4096,d=64: 0.656 ms vs 0.806 ms (profiles/r01_variants.txt)
+        rc = dkdv_launch<T, D, 32, 8>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+    } else {
+      rc = dkdv_launch<T, D, 32, 4>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+    }
+    if (rc) return rc;
   }
   if (stages & FA_BWD_STAGE_DQ) {
     const int nqb = (N + 127) / 128;
     hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nl, nd, dq, N, nqb, batch, causal, tau);
+                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, causal, tau);
     FA_HIP_TRY(hipGetLastError());
   }
   return FA_OK;
@@ -106,7 +123,7 @@ int check_common(int batch, int N, int d, int variant, int dtype) {
   if (batch <= 0 || N <= 0 || d <= 0) return set_err(FA_ERR_BAD_ARG, "batch, N and d must be positive");
   if (variant != FA_VARIANT_FA1 && variant != FA_VARIANT_FA2) return set_err(FA_ERR_BAD_ARG, "unknown variant");
   if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return set_err(FA_ERR_BAD_ARG, "unknown dtype");
-  if ((long)batch * N * d >= (1L << 40)) return set_err(FA_ERR_BAD_ARG, "tensor too large");
+  if ((long)N * 128 * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "N too large: one (batch*head) matrix must stay under 2 GiB");
   return FA_OK;
 }
 
@@ -168,7 +185,13 @@ void d2h_rows(float* dst, const float* src, size_t rows, int d, int dp, hipStrea
 extern "C" {
 
 const char* fa_mi355x_last_error(void) { return g_err; }
-const char* fa_mi355x_version(void) { return "flash_attn_mi355x 0.1 gfx950"; }
+const char* fa_mi355x_version(void) { return "flash_attn_mi355x 0.2 gfx950"; }
+
+int fa_mi355x_set_tuning(int key, int value) {
+  if (key < 0 || key >= 8) return set_err(FA_ERR_BAD_ARG, "unknown tuning key");
+  g_tuning[key] = value;
+  return FA_OK;
+}
 
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                   int d, int causal, int variant, int dtype, void* stream) {
@@ -288,7 +311,7 @@ int fa_mi355x_probe(const void* tile, const void* b, float* row_out, float* tr_o
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "probe supports d in {32, 64, 128}");
   hipStream_t st = (hipStream_t)stream;
 #define FA_PROBE(T, DD)                                                                                      \
-  hipLaunchKernelGGL((fa::probe_kernel<T, DD>), dim3(1), dim3(64), 0, st, (const T*)tile, (const T*)b, row_out, \
+  hipLaunchKernelGGL((fa::probe_kernel<T, DD>), dim3(1), dim3(256), 0, st, (const T*)tile, (const T*)b, row_out, \
                      tr_out, mma_out, swap_out)
   if (dtype == FA_DTYPE_BF16) {
     if (d == 32) FA_PROBE(fa::bf16_t, 32); else if (d == 64) FA_PROBE(fa::bf16_t, 64); else FA_PROBE(fa::bf16_t, 128);

@@ -1,5 +1,5 @@
-// MFMA "atoms" for gfx950 (MI355X, CDNA4): the four primitives every attention kernel here is
-// written in terms of, for bf16 (v_mfma_f32_32x32x16_bf16) and exact fp32 (v_mfma_f32_32x32x2_f32).
+// MFMA "atoms" for gfx950 (MI355X, CDNA4): the primitives every attention kernel here is written in terms
+// of, for bf16 (v_mfma_f32_32x32x16_bf16) and exact fp32 (v_mfma_f32_32x32x2_f32).
 //
 // Conventions (wave64, lane l: r = l & 31, h = l >> 5):
 //   * A "fragment" is 8 consecutive k-elements of one operand row: k = 16*kc + 8*h + j, j = 0..7.
@@ -11,7 +11,9 @@
 //   * pack(X, s) turns registers 8s..8s+7 into the fragment of k-chunk s for a following MFMA that sums
 //     over X's ROW index; the matching "transposed" fragment of the other operand (tr_frag) holds, in
 //     element j, row 16*s + 8*(j >> 2) + 4*h + (j & 3) of an LDS tile at column r.
-//   * LDS tile images are addressed in 16-byte chunks: off(row, ch).
+//   * LDS tile images are addressed in 16-byte chunks: off(row, ch).  Every read address splits into a
+//     per-lane part computed ONCE per kernel (RowAddr / TrAddr) and a compile-time constant that lands in
+//     the ds_read instruction's offset field: no address arithmetic in the tile loops.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,6 +49,8 @@ FA_DEV float xhalf_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+struct LaneAddr { int b[2]; };  // per-lane byte offsets inside a tile image (two XOR phases for bf16)
+
 template <typename T> struct Atom;
 
 // ---------------------------------------------------------------------------------------------
@@ -58,33 +62,63 @@ template <typename T> struct Atom;
 template <> struct Atom<bf16_t> {
   typedef bf16x8 frag;
   static constexpr int ESZ = 2;
-  static constexpr int CH_ELEMS = 8;  // elements per 16-byte chunk
   template <int D> static constexpr int tile_bytes(int rows) { return rows * D * 2; }
-  template <int D> static FA_DEV int off(int row, int ch) {
+  template <int D> static FA_DEV constexpr int off(int row, int ch) {
     return (D / 32) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
   }
   static FA_DEV frag zero() { frag z; for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.0f; return z; }
   static FA_DEV frag load_global(const bf16_t* p) { return *reinterpret_cast<const frag*>(p); }
-  template <int D> static FA_DEV frag row_frag(lds_char* tile, int row, int kc, int h) {
-    return *FA_LDS(frag, tile + off<D>(row, 2 * kc + h));
+
+  // row_frag(tile, a, row32, kc): 8 elements of row (row32 + r) at columns 16*kc + 8*h ..   (row32 % 32 == 0)
+  template <int D> static FA_DEV LaneAddr row_addr(int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    LaneAddr a;
+    const int rowpart = (D / 32) * 512 * (r >> 3) + 64 * (r & 7);
+    a.b[0] = rowpart + 16 * ((0 + h) ^ ((r >> 2) & 3));   // kc even: chunk & 3 = h
+    a.b[1] = rowpart + 16 * ((2 + h) ^ ((r >> 2) & 3));   // kc odd:  chunk & 3 = 2 + h
+    return a;
   }
-  // element j <- tile[rowbase + 8*(j>>2) + 4*h + (j&3)][32*ct + r]
-  template <int D> static FA_DEV frag tr_frag(lds_char* tile, int rowbase, int ct, int lane) {
+  template <int D> static FA_DEV frag row_frag(lds_char* tile, const LaneAddr& a, int row32, int kc) {
+    return *FA_LDS(frag, tile + a.b[kc & 1] + (D / 32) * 512 * (row32 >> 3) + 512 * (kc >> 1));
+  }
+  // tr_frag(tile, a, rowbase, ct): element j <- tile[rowbase + 8*(j>>2) + 4*h + (j&3)][32*ct + r]  (rowbase % 16 == 0)
+  template <int D> static FA_DEV LaneAddr tr_addr(int lane) {
     const int i = lane & 15, qq = i >> 2, p = i & 3, dsel = (lane >> 4) & 1, h = lane >> 5;
-    const int c = 4 * ct + 2 * dsel + (p >> 1);
-    const int r0 = rowbase + 4 * h + qq;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, tile + off<D>(r0, c) + 8 * (p & 1)));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, tile + off<D>(r0 + 8, c) + 8 * (p & 1)));
+    LaneAddr a;
+    const int c = 2 * dsel + (p >> 1);
+    a.b[0] = 64 * (4 * h + qq) + 16 * (c ^ h) + 8 * (p & 1);         // rows rowbase + 4h + qq      ((row>>2)&3 = h)
+    a.b[1] = 64 * (4 * h + qq) + 16 * (c ^ (h + 2)) + 8 * (p & 1);   // rows rowbase + 8 + 4h + qq  ((row>>2)&3 = h+2)
+    return a;
+  }
+  template <int D> static FA_DEV frag tr_frag(lds_char* tile, const LaneAddr& a, int rowbase, int ct) {
+    const int k = (D / 32) * 512 * (rowbase >> 3) + 512 * ct;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, tile + a.b[0] + k));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, tile + a.b[1] + k + (D / 32) * 512));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
-  static FA_DEV frag pack(const f32x16& x, int s) {
+  static FA_DEV frag pack(const f32x16& x, int s) {   // four v_cvt_pk_bf16_f32, no repacking
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    u4 u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 pr = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
+      u[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+    }
+    return __builtin_bit_cast(frag, u);
+  }
+  static FA_DEV frag scale(const frag& x, float c) {   // one rounding to bf16 per element
     frag f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (bf16_t)x[8 * s + j];
+    for (int j = 0; j < 8; ++j) f[j] = (bf16_t)((float)x[j] * c);
     return f;
   }
+  static FA_DEV frag ones() { frag f; for (int j = 0; j < 8; ++j) f[j] = (bf16_t)1.0f; return f; }
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  // d = a.b + c0 with c0 left intact (row constants ride in as the accumulator input)
+  static FA_DEV void mma_c(f32x16& d, const frag& a, const frag& b, const f32x16& c0) {
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
   }
 };
 
@@ -95,28 +129,37 @@ template <> struct Atom<bf16_t> {
 template <> struct Atom<float> {
   typedef f32x8 frag;
   static constexpr int ESZ = 4;
-  static constexpr int CH_ELEMS = 4;
   template <int D> static constexpr int tile_bytes(int rows) { return rows * (D + 4) * 4; }
-  template <int D> static FA_DEV int off(int row, int ch) { return row * (D + 4) * 4 + ch * 16; }
+  template <int D> static FA_DEV constexpr int off(int row, int ch) { return row * (D + 4) * 4 + ch * 16; }
   static FA_DEV frag zero() { frag z; for (int j = 0; j < 8; ++j) z[j] = 0.0f; return z; }
   static FA_DEV frag load_global(const float* p) {
     f32x4 a = *reinterpret_cast<const f32x4*>(p);
     f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   }
-  template <int D> static FA_DEV frag row_frag(lds_char* tile, int row, int kc, int h) {
-    f32x4 a = *FA_LDS(f32x4, tile + off<D>(row, 4 * kc + 2 * h));
-    f32x4 b = *FA_LDS(f32x4, tile + off<D>(row, 4 * kc + 2 * h + 1));
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-  }
-  template <int D> static FA_DEV frag tr_frag(lds_char* tile, int rowbase, int ct, int lane) {
+  template <int D> static FA_DEV LaneAddr row_addr(int lane) {
     const int r = lane & 31, h = lane >> 5;
+    LaneAddr a;
+    a.b[0] = a.b[1] = (r * (D + 4) + 8 * h) * 4;
+    return a;
+  }
+  template <int D> static FA_DEV frag row_frag(lds_char* tile, const LaneAddr& a, int row32, int kc) {
+    const int k = (row32 * (D + 4) + 16 * kc) * 4;
+    f32x4 x = *FA_LDS(f32x4, tile + a.b[0] + k);
+    f32x4 y = *FA_LDS(f32x4, tile + a.b[0] + k + 16);
+    return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  template <int D> static FA_DEV LaneAddr tr_addr(int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    LaneAddr a;
+    a.b[0] = a.b[1] = (4 * h * (D + 4) + r) * 4;
+    return a;
+  }
+  template <int D> static FA_DEV frag tr_frag(lds_char* tile, const LaneAddr& a, int rowbase, int ct) {
     frag f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int row = rowbase + 8 * (j >> 2) + 4 * h + (j & 3);
-      f[j] = *FA_LDS(float, tile + row * (D + 4) * 4 + (32 * ct + r) * 4);
-    }
+    for (int j = 0; j < 8; ++j)
+      f[j] = *FA_LDS(float, tile + a.b[0] + ((rowbase + 8 * (j >> 2) + (j & 3)) * (D + 4) + 32 * ct) * 4);
     return f;
   }
   static FA_DEV frag pack(const f32x16& x, int s) {
@@ -125,40 +168,72 @@ template <> struct Atom<float> {
     for (int j = 0; j < 8; ++j) f[j] = x[8 * s + j];
     return f;
   }
+  static FA_DEV frag scale(const frag& x, float c) { return x * c; }
+  static FA_DEV frag ones() { frag f; for (int j = 0; j < 8; ++j) f[j] = 1.0f; return f; }
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
   }
+  static FA_DEV void mma_c(f32x16& d, const frag& a, const frag& b, const f32x16& c0) {
+    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c0, 0, 0, 0);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], d, 0, 0, 0);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
-// Register-staged global -> LDS tile copy, split into an early issue (load) and a late LDS write
-// (store) so the HBM/L2 latency hides under the MFMA phase in between.  Rows >= nrows read as zero.
+// Buffer resource over one (batch*head) matrix: loads past its end return zero, so ragged tails need no
+// guards, and the tile's row offset rides in the scalar soffset operand (no per-tile address VALU).
+// Built from kernel arguments and blockIdx-derived scalars only, so it stays in SGPRs.
 // ---------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+FA_DEV rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// Register-staged global -> LDS tile copy of ROWS x D elements by NT threads, split into an early issue (load)
+// and a late LDS write (store) so the HBM/L2 latency hides under the MFMA phase in between.
 template <typename T, int D, int ROWS, int NT> struct TileStager {
   static constexpr int CPR = D * (int)sizeof(T) / 16;   // 16-B chunks per row
   static constexpr int NCH = ROWS * CPR;
   static constexpr int PER = (NCH + NT - 1) / NT;
+  static constexpr int RSTEP = NT / CPR;                // rows between a thread's consecutive chunks
+  static_assert(NT % CPR == 0, "threads must tile whole rows");
+  static_assert(sizeof(T) == 4 || RSTEP % 16 == 0 || PER == 1, "row step must keep the swizzle phase");
   u32x4 regs[PER];
-  // g: pointer to row 0 of this (batch*head) matrix; row0: first row of the tile.
-  FA_DEV void load(const T* g, int row0, int nrows, int tid) {
+  int voff;       // byte offset of this thread's first chunk inside the global tile
+  int lds_off;    // byte offset of this thread's first chunk inside the LDS image
+  bool live;      // this thread has a chunk at all (NCH < NT)
+  FA_DEV void init(int tid) {
+    int row = tid / CPR, ch = tid % CPR;
+    if constexpr (sizeof(T) == 2 && CPR >= 8) {
+      // bf16 image: a ds_write_b128 lane group (8 consecutive lanes) must cover 128 distinct bytes mod 128:
+      // two adjacent rows x four chunks of one 32-column subtile (rows are 64 B apart inside a subtile).
+      const int g = tid >> 3;
+      row = 2 * (g / (CPR / 4)) + ((tid >> 2) & 1);
+      ch = 4 * (g % (CPR / 4)) + (tid & 3);
+    }
+    voff = (row * D) * (int)sizeof(T) + ch * 16;
+    lds_off = Atom<T>::template off<D>(row, ch);
+    live = (NCH >= NT) || tid < NCH;
+  }
+  // row0 (wave-uniform): first row of the tile inside the matrix the resource covers
+  FA_DEV void load(rsrc_t rs, int row0) {
+    const int soff = row0 * D * (int)sizeof(T);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / CPR, ch = c % CPR;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if ((NCH % NT == 0 || c < NCH) && row0 + row < nrows)
-        v = *reinterpret_cast<const u32x4*>(g + (size_t)(row0 + row) * D + ch * (16 / (int)sizeof(T)));
+      if (NCH % NT == 0 || live)
+        v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                          rs, voff + i * RSTEP * D * (int)sizeof(T), soff, 0));
       regs[i] = v;
     }
   }
-  FA_DEV void store(lds_char* tile, int tid) const {
+  FA_DEV void store(lds_char* tile) const {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / CPR, ch = c % CPR;
-      if (NCH % NT == 0 || c < NCH) *FA_LDS(u32x4, tile + Atom<T>::template off<D>(row, ch)) = regs[i];
-    }
+    for (int i = 0; i < PER; ++i)
+      if (NCH % NT == 0 || live)
+        *FA_LDS(u32x4, tile + lds_off + Atom<T>::template off<D>(i * RSTEP, 0)) = regs[i];
   }
 };
 

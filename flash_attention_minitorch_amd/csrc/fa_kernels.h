@@ -13,11 +13,17 @@
 // (half) rows of the softmax: row max / row sum are register reductions plus one v_permlane32_swap, and the
 // exponentiated tile is directly the B operand of O^T += V^T P^T (no LDS round trip for P).
 //
-// Backward = preprocess (delta = rowsum(dO*O), -L/tau) + a key-stationary dK/dV kernel (S, dP with the KEY on the
-// lane; P and dS feed dV^T += dO^T P and dK^T += Q^T dS from registers) + a query-stationary dQ kernel
+// Backward = preprocess (delta = rowsum(dO*O), -L*log2e) + a key-stationary dK/dV kernel (S, dP with the KEY on
+// the lane; P and dS feed dV^T += dO^T P and dK^T += Q^T dS from registers) + a query-stationary dQ kernel
 // (S^T, dP^T with the query on the lane; dQ^T += K^T dS^T).  No atomics: results are bitwise reproducible
 // (the reference's FA-2 backward uses atomicAdd for dQ, src/flash_attn2_bw.cu:228).
+//
+// Tile loops are unrolled by two so the LDS double-buffer index is a compile-time constant: every LDS address is
+// a per-lane register computed once plus an instruction immediate, and every global tile load is a buffer load
+// whose tile offset is a scalar operand (out-of-range rows read as zero) -- no address VALU inside the loops.
 #pragma once
+#include <type_traits>
+
 #include "fa_atoms.h"
 
 namespace fa {
@@ -26,9 +32,37 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int AUX_FA1 = 1;  // l = sum exp(s - m), m = row max            (src/flash_attn_fw.cu:259-276)
 constexpr int AUX_FA2 = 2;  // l = logsumexp, m untouched                  (src/flash_attn2_fw.cu:279-294)
 
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <typename T> FA_DEV typename Atom<T>::frag load_frag_buf(rsrc_t rs, int byte_off);
+template <> FA_DEV bf16x8 load_frag_buf<bf16_t>(rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+template <> FA_DEV f32x8 load_frag_buf<float>(rsrc_t rs, int byte_off) {
+  f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+  f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16, 0, 0));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+FA_DEV f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Forward
+// Forward.  P = exp2(c*s - c*m_ref) with c = tau*log2(e) applied in fp32 (one fma per score: pre-scaling Q or K
+// in bf16 was measured to cost up to 3.7e-3 max-abs on O at small N -- the rounding is the same for every key of a
+// row, so it does not average out).  m_ref is a per-row REFERENCE, not the running maximum: it is only moved
+// (O, l rescaled) when a row maximum outgrows it by more than MAX_DEFER in log2 units, so P stays <= 2^MAX_DEFER,
+// which fp32 / bf16 hold at full relative precision, and the steady state has no rescale work at all.
+// Row sums stay on the VALU in fp32: summing the bf16-rounded P on the MFMA (ones . P^T) was measured 4 % faster
+// but puts P's 2^-9 quantisation into L = m + log(l), which the backward then exponentiates (dV error 2.7e-3 on
+// causal rows with few keys).  The MFMA form is kept behind MFMA_SUM for experiments.
 // ---------------------------------------------------------------------------------------------
+constexpr float MAX_DEFER = 6.0f;
+
 template <typename T, int D, int BN>
 __global__ void __launch_bounds__(256)
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
@@ -38,58 +72,68 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
   constexpr int TB = A::template tile_bytes<D>(BN);
+  constexpr bool MFMA_SUM = false;
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
   int bh, qb;
   map_block(blockIdx.x, BH, nqb, bh, qb);
   if (causal) qb = nqb - 1 - qb;  // heaviest query blocks first
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
   const size_t base = (size_t)bh * N * D;
-  const T* kg = k + base;
-  const T* vg = v + base;
+  const uint32_t mat_bytes = (uint32_t)N * D * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
   const float c = tau * LOG2E;
 
   frag qf[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc)
-    qf[kc] = qvalid ? A::load_global(q + base + (size_t)qrow * D + 16 * kc + 8 * h) : A::zero();
+    qf[kc] = load_frag_buf<T>(qrs, (qrow * D + 16 * kc + 8 * h) * (int)sizeof(T));
 
   f32x16 acc_o[DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_o[dt][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int dt = 0; dt < DT; ++dt) acc_o[dt] = zero16();
+  f32x16 acc_l = zero16();   // bf16 path: every register holds the row sum (ones . P^T)
+  float m_ref = 0.f, nmc = 0.f, m_true = -INFINITY, l_run = 0.f;   // raw score units; nmc = -m_ref * c
+  const frag ones = A::ones();
 
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
   const int kmax = causal ? min(N, qb * 128 + 128) : N;
   const int nt = (kmax + BN - 1) / BN;
   TileStager<T, D, BN, 256> sk, sv;
-  sk.load(kg, 0, N, tid);
-  sv.load(vg, 0, N, tid);
-  sk.store(smem, tid);
-  sv.store(smem + 2 * TB, tid);
+  sk.init(tid);
+  sv.init(tid);
+  sk.load(krs, 0);
+  sv.load(vrs, 0);
+  sk.store(smem);
+  sv.store(smem + 2 * TB);
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  auto tile = [&](auto par, auto first_c, int t) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr bool FIRST = decltype(first_c)::value != 0;
     const int kbase = t * BN;
-    if (t + 1 < nt) {
-      sk.load(kg, kbase + BN, N, tid);
-      sv.load(vg, kbase + BN, N, tid);
+    const bool more = t + 1 < nt;
+    if (more) {
+      sk.load(krs, kbase + BN);
+      sv.load(vrs, kbase + BN);
     }
-    lds_char* tk = smem + (t & 1) * TB;
-    lds_char* tv = smem + (2 + (t & 1)) * TB;
+    lds_char* tk = smem + PAR * TB;
+    lds_char* tv = smem + (2 + PAR) * TB;
     const bool active = !causal || kbase <= q0 + 31;  // wave-uniform
     if (active) {
       f32x16 s[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
+        s[kt] = zero16();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) A::mma(s[kt], A::template row_frag<D>(tk, 32 * kt + r, kc, h), qf[kc]);
+        for (int kc = 0; kc < KC; ++kc) A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
       }
       const bool need_mask = (kbase + BN > N) || (causal && kbase + BN - 1 > q0);  // wave-uniform
       if (need_mask) {
@@ -106,27 +150,36 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt][i]);
-      mx = xhalf_max(mx);
-      const float m_new = fmaxf(m_run, mx);
-      const float mc = m_new * c;
-      const float alpha = __builtin_amdgcn_exp2f(m_run * c - mc);
+      mx = xhalf_max(mx);                      // row maximum of this tile (raw score units)
+      m_true = fmaxf(m_true, mx);
+      float alpha = 1.0f;
+      // move the reference when some row outgrew it (always on the first tile: m_ref = its row max)
+      if (FIRST || __any(__builtin_fmaf(mx, c, nmc) > MAX_DEFER)) {
+        const float delta = FIRST ? mx : fmaxf(mx - m_ref, 0.f);
+        if (!FIRST) {
+          alpha = __builtin_amdgcn_exp2f(-delta * c);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
+          if (MFMA_SUM) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_l[i] *= alpha;
+          }
+        }
+        m_ref += delta;
+        nmc = -m_ref * c;
+      }
       float rowsum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, -mc));
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nmc));
           s[kt][i] = p;
-          rowsum += p;
+          if (!MFMA_SUM) rowsum += p;
         }
-      l_run = l_run * alpha + rowsum;
-      if (!__all(m_new == m_run)) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
-      }
-      m_run = m_new;
+      if (!MFMA_SUM) l_run = l_run * alpha + rowsum;
       frag pf[KT][2];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
@@ -134,21 +187,30 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         pf[kt][1] = A::pack(s[kt], 1);
       }
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (MFMA_SUM) A::mma(acc_l, ones, pf[kt][s2]);
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-            A::mma(acc_o[dt], A::template tr_frag<D>(tv, 32 * kt + 16 * s2, dt, lane), pf[kt][s2]);
+          for (int dt = 0; dt < DT; ++dt)
+            A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pf[kt][s2]);
+        }
     }
-    if (t + 1 < nt) {
-      sk.store(smem + ((t + 1) & 1) * TB, tid);
-      sv.store(smem + (2 + ((t + 1) & 1)) * TB, tid);
+    if (more) {
+      sk.store(smem + (PAR ^ 1) * TB);
+      sv.store(smem + (2 + (PAR ^ 1)) * TB);
     }
     __syncthreads();
+  };
+  tile(ic<0>{}, ic<1>{}, 0);
+  int t = 1;
+  for (; t + 1 < nt; t += 2) {
+    tile(ic<1>{}, ic<0>{}, t);
+    tile(ic<0>{}, ic<0>{}, t + 1);
   }
+  if (t < nt) tile(ic<1>{}, ic<0>{}, t);
 
-  const float l_tot = xhalf_sum(l_run);
+  const float l_tot = MFMA_SUM ? acc_l[0] : xhalf_sum(l_run);   // sum of exp2(s - m_ref)
   const float inv = 1.0f / l_tot;
   if (qvalid) {
     float* orow = o + base + (size_t)qrow * D;
@@ -162,25 +224,27 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
       }
     if (h == 0) {
       const size_t ri = (size_t)bh * N + qrow;
-      if (aux_mode == AUX_FA1) {
-        aux_l[ri] = l_tot;
-        aux_m[ri] = m_run * tau;
+      if (aux_mode == AUX_FA1) {   // l = sum exp(tau*s - m), m = tau * rowmax(s)
+        aux_l[ri] = l_tot * __builtin_amdgcn_exp2f((m_ref - m_true) * c);
+        aux_m[ri] = m_true * tau;
       } else {
-        aux_l[ri] = m_run * tau + __logf(l_tot);
+        aux_l[ri] = m_ref * tau + __logf(l_tot);
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward preprocess: nd = -rowsum(dO * O), nl = -L / tau with L = m + log(l) (FA-1 side outputs) or L = l (FA-2).
-// The reference recomputes D_i per (i, j) tile (src/flash_attn_bw.cu:194-197); once per row gives the same value.
+// Backward preprocess: ndelta = -rowsum(dO * O), nlc = -L * log2(e) with L = m + log(l) (FA-1 side outputs) or
+// L = l (FA-2), so that P = exp2(tau*log2e * (q.k) + nlc) and dS = P * (dO.V^T + ndelta): both row constants
+// enter the main kernels as MFMA accumulator inputs.  The reference recomputes D_i per (i, j) tile
+// (src/flash_attn_bw.cu:194-197); once per row gives the same value.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
 __global__ void __launch_bounds__(256)
 bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ l,
-                const float* __restrict__ m, float* __restrict__ nl, float* __restrict__ nd, long rows, int aux_mode,
-                float inv_tau) {
+                const float* __restrict__ m, float* __restrict__ nlc, float* __restrict__ ndelta, long rows,
+                int aux_mode) {
   constexpr int LPR = D / 8;  // lanes per row, 8 elements each
   constexpr int RPB = 256 / LPR;
   const int tid = threadIdx.x;
@@ -198,133 +262,149 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 #pragma unroll
   for (int off = LPR / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
   if (row < rows && part == 0) {
-    nd[row] = -sum;
+    ndelta[row] = -sum;
     const float L = (aux_mode == AUX_FA1) ? (m[row] + __logf(l[row])) : l[row];
-    nl[row] = -L * inv_tau;
+    nlc[row] = -L * LOG2E;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward dK / dV: a workgroup = 4 waves = 4*KPW keys of one (batch*head); each wave keeps K, V fragments and
+// Backward dK / dV: a workgroup = NW waves = NW*KPW keys of one (batch*head); each wave keeps K, V fragments and
 // the dK^T, dV^T accumulators of its KPW keys in registers while the workgroup sweeps 32-row query slices
-// (Q, dO tiles + their -L/tau, -delta staged in LDS, double buffered).
+// (Q, dO tiles + their nlc, delta staged in LDS, double buffered).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int KPW>
-__global__ void __launch_bounds__(256)
+template <typename T, int D, int KPW, int NW>
+__global__ void __launch_bounds__(NW * 64)
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
-                const float* __restrict__ nl, const float* __restrict__ nd, float* __restrict__ dk,
+                const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
                 float* __restrict__ dv, int N, int nkb, int BH, int causal, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
-  constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = 4 * KPW;
+  constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = NW * KPW, NT = NW * 64;
   constexpr int TB = A::template tile_bytes<D>(32);
-  constexpr int BUF = 2 * TB + 256;  // Q tile, dO tile, 32 x nl, 32 x nd
+  constexpr int BUF = 2 * TB + 256;  // Q tile, dO tile, 32 x nlc, 32 x delta
   __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
   lds_char* smem = (lds_char*)smem_raw;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh, kb;
   map_block(blockIdx.x, BH, nkb, bh, kb);
   const int kb0 = kb * BK, kw0 = kb0 + w * KPW;
   const size_t base = (size_t)bh * N * D;
-  const T* qg = q + base;
-  const T* dog = dout + base;
-  const float* nlg = nl + (size_t)bh * N;
-  const float* ndg = nd + (size_t)bh * N;
+  const uint32_t mat_bytes = (uint32_t)N * D * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
+  const float* nlg = nlc + (size_t)bh * N;
+  const float* deg = ndelta + (size_t)bh * N;
   const float c = tau * LOG2E;
 
   frag kf[KT][KC], vf[KT][KC];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    const int key = kw0 + 32 * kt + r;
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const size_t off = base + (size_t)key * D + 16 * kc + 8 * h;
-      kf[kt][kc] = key < N ? A::load_global(k + off) : A::zero();
-      vf[kt][kc] = key < N ? A::load_global(v + off) : A::zero();
+      const int off = ((kw0 + 32 * kt + r) * D + 16 * kc + 8 * h) * (int)sizeof(T);  // rows >= N read as zero
+      kf[kt][kc] = load_frag_buf<T>(krs, off);
+      vf[kt][kc] = load_frag_buf<T>(vrs, off);
     }
-  }
   f32x16 acc_dk[DT][KT], acc_dv[DT][KT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acc_dk[dt][kt][i] = 0.f;
-        acc_dv[dt][kt][i] = 0.f;
-      }
+    for (int kt = 0; kt < KT; ++kt) {
+      acc_dk[dt][kt] = zero16();
+      acc_dv[dt][kt] = zero16();
+    }
 
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
   const int nqi = (N + 31) / 32;
   const int qi_begin = causal ? (kb0 / 32) : 0;  // query slices entirely above the key block are fully masked
-  TileStager<T, D, 32, 256> sq, sdo;
-  float st_nl = 0.f, st_nd = 0.f;
+  TileStager<T, D, 32, NT> sq, sdo;
+  sq.init(tid);
+  sdo.init(tid);
+  float st_nl = 0.f, st_de = 0.f;
   auto stage_load = [&](int qi) {
-    sq.load(qg, qi * 32, N, tid);
-    sdo.load(dog, qi * 32, N, tid);
+    sq.load(qrs, qi * 32);
+    sdo.load(dors, qi * 32);
     if (tid < 32) {
       const int row = qi * 32 + tid;
       st_nl = row < N ? nlg[row] : 0.f;
-      st_nd = row < N ? ndg[row] : 0.f;
+      st_de = row < N ? deg[row] : 0.f;
     }
   };
-  auto stage_store = [&](int buf) {
-    lds_char* b = smem + buf * BUF;
-    sq.store(b, tid);
-    sdo.store(b + TB, tid);
+  auto stage_store = [&](lds_char* b) {
+    sq.store(b);
+    sdo.store(b + TB);
     if (tid < 32) {
       *FA_LDS(float, b + 2 * TB + 4 * tid) = st_nl;
-      *FA_LDS(float, b + 2 * TB + 128 + 4 * tid) = st_nd;
+      *FA_LDS(float, b + 2 * TB + 128 + 4 * tid) = st_de;
     }
   };
   if (qi_begin < nqi) {
     stage_load(qi_begin);
-    stage_store(0);
+    stage_store(smem);
   }
   __syncthreads();
 
-  for (int qi = qi_begin; qi < nqi; ++qi) {
-    const int it = qi - qi_begin;
-    if (qi + 1 < nqi) stage_load(qi + 1);
-    lds_char* buf = smem + (it & 1) * BUF;
+  auto slice = [&](auto par, int qi) {
+    constexpr int PAR = decltype(par)::value;
+    const bool more = qi + 1 < nqi;
+    if (more) stage_load(qi + 1);
+    lds_char* buf = smem + PAR * BUF;
     lds_char* tq = buf;
     lds_char* tdo = buf + TB;
     const int qi0 = qi * 32;
     const bool active = (kw0 < N) && (!causal || qi0 + 31 >= kw0);  // wave-uniform
     if (active) {
-      f32x16 s[KT], dp[KT];
+      // register i of lane half h is query qi0 + acc_row(i, h): its nlc / -delta come from LDS (broadcast reads);
+      // -delta enters the dP tile as the accumulator input of its first MFMA
+      f32x16 nl16, nd16;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 a = *FA_LDS(f32x4, buf + 2 * TB + 4 * (8 * g + 4 * h));
-        const f32x4 b = *FA_LDS(f32x4, buf + 2 * TB + 128 + 4 * (8 * g + 4 * h));
+        const f32x4 a = *FA_LDS(f32x4, buf + 2 * TB + 16 * h + 32 * g);
+        const f32x4 b = *FA_LDS(f32x4, buf + 2 * TB + 128 + 16 * h + 32 * g);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            s[kt][4 * g + j] = a[j];
-            dp[kt][4 * g + j] = b[j];
-          }
+        for (int j = 0; j < 4; ++j) {
+          nl16[4 * g + j] = a[j];
+          nd16[4 * g + j] = b[j];
+        }
       }
+      f32x16 s[KT], dp[KT];
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const frag aq = A::template row_frag<D>(tq, r, kc, h);
-        const frag ado = A::template row_frag<D>(tdo, r, kc, h);
+        const frag aq = A::template row_frag<D>(tq, ra, 0, kc);
+        const frag ado = A::template row_frag<D>(tdo, ra, 0, kc);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          A::mma(s[kt], aq, kf[kt][kc]);
-          A::mma(dp[kt], ado, vf[kt][kc]);
+          if (kc == 0) {   // -delta rides in as dP's accumulator input (exact); S starts from zero
+            A::mma_c(s[kt], aq, kf[kt][kc], zero16());
+            A::mma_c(dp[kt], ado, vf[kt][kc], nd16);
+          } else {
+            A::mma(s[kt], aq, kf[kt][kc]);
+            A::mma(dp[kt], ado, vf[kt][kc]);
+          }
         }
       }
       const bool need_mask = causal && (kw0 + KPW - 1 > qi0);  // wave-uniform
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f(s[kt][i] * c);
-          if (need_mask && (kw0 + 32 * kt + r > qi0 + acc_row(i, h))) p = 0.f;
-          s[kt][i] = p;
-          dp[kt][i] = p * dp[kt][i];
-        }
+        for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nl16[i]));
+      if (need_mask) {   // diagonal slices only (scalar branch)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kw0 + 32 * kt + r > qi0 + acc_row(i, h)) s[kt][i] = 0.f;
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[kt][i] = s[kt][i] * dp[kt][i];
       frag pf[KT][2], dsf[KT][2];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -337,8 +417,8 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const frag adoT = A::template tr_frag<D>(tdo, 16 * s2, dt, lane);
-          const frag aqT = A::template tr_frag<D>(tq, 16 * s2, dt, lane);
+          const frag adoT = A::template tr_frag<D>(tdo, ta, 16 * s2, dt);
+          const frag aqT = A::template tr_frag<D>(tq, ta, 16 * s2, dt);
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
             A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
@@ -346,9 +426,15 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           }
         }
     }
-    if (qi + 1 < nqi) stage_store((it + 1) & 1);
+    if (more) stage_store(smem + (PAR ^ 1) * BUF);
     __syncthreads();
+  };
+  int qi = qi_begin;
+  for (; qi + 1 < nqi; qi += 2) {
+    slice(ic<0>{}, qi);
+    slice(ic<1>{}, qi + 1);
   }
+  if (qi < nqi) slice(ic<0>{}, qi);
 
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -377,7 +463,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 template <typename T, int D, int BN>
 __global__ void __launch_bounds__(256)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
-              const float* __restrict__ nl, const float* __restrict__ nd, float* __restrict__ dq, int N, int nqb,
+              const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
               int BH, int causal, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
@@ -386,76 +472,92 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh, qb;
   map_block(blockIdx.x, BH, nqb, bh, qb);
   if (causal) qb = nqb - 1 - qb;
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
   const size_t base = (size_t)bh * N * D;
-  const T* kg = k + base;
-  const T* vg = v + base;
+  const uint32_t mat_bytes = (uint32_t)N * D * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
   const float c = tau * LOG2E;
 
   frag qf[KC], dof[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const size_t off = base + (size_t)qrow * D + 16 * kc + 8 * h;
-    qf[kc] = qvalid ? A::load_global(q + off) : A::zero();
-    dof[kc] = qvalid ? A::load_global(dout + off) : A::zero();
+    const int off = (qrow * D + 16 * kc + 8 * h) * (int)sizeof(T);
+    qf[kc] = load_frag_buf<T>(qrs, off);
+    dof[kc] = load_frag_buf<T>(dors, off);
   }
-  const float nlq = qvalid ? nl[(size_t)bh * N + qrow] : 0.f;
-  const float ndq = qvalid ? nd[(size_t)bh * N + qrow] : 0.f;
+  // this lane's row constants; -delta, in every register, is the accumulator input of the dP^T tiles
+  const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] : 0.f;
+  const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  f32x16 nd16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nd16[i] = ndq;
 
   f32x16 acc[DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = zero16();
 
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
   const int kmax = causal ? min(N, qb * 128 + 128) : N;
   const int nt = (kmax + BN - 1) / BN;
   TileStager<T, D, BN, 256> sk, sv;
-  sk.load(kg, 0, N, tid);
-  sv.load(vg, 0, N, tid);
-  sk.store(smem, tid);
-  sv.store(smem + 2 * TB, tid);
+  sk.init(tid);
+  sv.init(tid);
+  sk.load(krs, 0);
+  sv.load(vrs, 0);
+  sk.store(smem);
+  sv.store(smem + 2 * TB);
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  auto tile = [&](auto par, int t) {
+    constexpr int PAR = decltype(par)::value;
     const int kbase = t * BN;
-    if (t + 1 < nt) {
-      sk.load(kg, kbase + BN, N, tid);
-      sv.load(vg, kbase + BN, N, tid);
+    const bool more = t + 1 < nt;
+    if (more) {
+      sk.load(krs, kbase + BN);
+      sv.load(vrs, kbase + BN);
     }
-    lds_char* tk = smem + (t & 1) * TB;
-    lds_char* tv = smem + (2 + (t & 1)) * TB;
+    lds_char* tk = smem + PAR * TB;
+    lds_char* tv = smem + (2 + PAR) * TB;
     const bool active = !causal || kbase <= q0 + 31;
     if (active) {
       f32x16 s[KT], dp[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
+        A::mma_c(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, 0), qf[0], zero16());
+        A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], nd16);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          s[kt][i] = nlq;
-          dp[kt][i] = ndq;
-        }
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          A::mma(s[kt], A::template row_frag<D>(tk, 32 * kt + r, kc, h), qf[kc]);
-          A::mma(dp[kt], A::template row_frag<D>(tv, 32 * kt + r, kc, h), dof[kc]);
+        for (int kc = 1; kc < KC; ++kc) {
+          A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
+          A::mma(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, kc), dof[kc]);
         }
       }
       const bool need_mask = causal && (kbase + BN - 1 > q0);
       frag dsf[KT][2];
 #pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nlq));
+      if (need_mask) {   // diagonal tiles only (scalar branch)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kbase + 32 * kt + acc_row(i, h) > qrow) s[kt][i] = 0.f;
+      }
+#pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f(s[kt][i] * c);
-          if (need_mask && (kbase + 32 * kt + acc_row(i, h) > qrow)) p = 0.f;
-          dp[kt][i] = p * dp[kt][i];
-        }
+        for (int i = 0; i < 16; ++i) dp[kt][i] = s[kt][i] * dp[kt][i];
         dsf[kt][0] = A::pack(dp[kt], 0);
         dsf[kt][1] = A::pack(dp[kt], 1);
       }
@@ -465,14 +567,20 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2)
-            A::mma(acc[dt], A::template tr_frag<D>(tk, 32 * kt + 16 * s2, dt, lane), dsf[kt][s2]);
+            A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dsf[kt][s2]);
     }
-    if (t + 1 < nt) {
-      sk.store(smem + ((t + 1) & 1) * TB, tid);
-      sv.store(smem + (2 + ((t + 1) & 1)) * TB, tid);
+    if (more) {
+      sk.store(smem + (PAR ^ 1) * TB);
+      sv.store(smem + (2 + (PAR ^ 1)) * TB);
     }
     __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile(ic<0>{}, t);
+    tile(ic<1>{}, t + 1);
   }
+  if (t < nt) tile(ic<0>{}, t);
 
   if (qvalid) {
     float* row = dq + base + (size_t)qrow * D;
@@ -489,9 +597,10 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 
 // ---------------------------------------------------------------------------------------------
 // Layout probes (tests only): dump what the atoms read so the lane maps are checked against exact data.
+// 256 threads stage the tile (as the real kernels do); wave 0 runs the probes.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 probe_kernel(const T* __restrict__ tile_in /*[64][D]*/, const T* __restrict__ b_in /*[32][D]*/,
              float* __restrict__ row_out /*[D/16][64][8]*/, float* __restrict__ tr_out /*[D/32][4][64][8]*/,
              float* __restrict__ mma_out /*[2][64][16]*/, float* __restrict__ swap_out /*[2][64]*/) {
@@ -499,29 +608,36 @@ probe_kernel(const T* __restrict__ tile_in /*[64][D]*/, const T* __restrict__ b_
   typedef typename A::frag frag;
   __shared__ __attribute__((aligned(16))) char smem_raw[A::template tile_bytes<D>(64)];
   lds_char* smem = (lds_char*)smem_raw;
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-  TileStager<T, D, 64, 64> st;
-  st.load(tile_in, 0, 64, lane);
-  st.store(smem, lane);
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  TileStager<T, D, 64, 256> st;
+  st.init(tid);
+  st.load(make_rsrc(tile_in, 64 * D * sizeof(T)), 0);
+  st.store(smem);
   __syncthreads();
+  if (tid >= 64) return;
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+#pragma unroll
   for (int kc = 0; kc < D / 16; ++kc) {
-    frag f = A::template row_frag<D>(smem, 32 + r, kc, h);  // rows 32..63
+    frag f = A::template row_frag<D>(smem, ra, 32, kc);  // rows 32..63
     for (int j = 0; j < 8; ++j) row_out[(kc * 64 + lane) * 8 + j] = (float)f[j];
   }
+#pragma unroll
   for (int ct = 0; ct < D / 32; ++ct)
+#pragma unroll
     for (int s = 0; s < 4; ++s) {
-      frag f = A::template tr_frag<D>(smem, 16 * s, ct, lane);
+      frag f = A::template tr_frag<D>(smem, ta, 16 * s, ct);
       for (int j = 0; j < 8; ++j) tr_out[((ct * 4 + s) * 64 + lane) * 8 + j] = (float)f[j];
     }
-  // X = tile[0:32] . b^T  (32 x 32, sum over D); then Y = tile[0:32, 0:32]^T-style product through pack/tr_frag:
+  // X = tile[0:32] . b^T  (32 x 32, sum over D); then through pack / tr_frag:
   // Y[c][n] = sum_m tile[m][c] * X[m][n]  for c < 32  (A operand = tr_frag of the tile, B operand = pack(X)).
-  f32x16 x;
-  for (int i = 0; i < 16; ++i) x[i] = 0.f;
+  f32x16 x = zero16();
+#pragma unroll
   for (int kc = 0; kc < D / 16; ++kc)
-    A::mma(x, A::template row_frag<D>(smem, r, kc, h), A::load_global(b_in + (size_t)r * D + 16 * kc + 8 * h));
-  f32x16 y;
-  for (int i = 0; i < 16; ++i) y[i] = 0.f;
-  for (int s = 0; s < 2; ++s) A::mma(y, A::template tr_frag<D>(smem, 16 * s, 0, lane), A::pack(x, s));
+    A::mma(x, A::template row_frag<D>(smem, ra, 0, kc), A::load_global(b_in + (size_t)r * D + 16 * kc + 8 * h));
+  f32x16 y = zero16();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) A::mma(y, A::template tr_frag<D>(smem, ta, 16 * s, 0), A::pack(x, s));
   for (int i = 0; i < 16; ++i) {
     mma_out[lane * 16 + i] = x[i];
     mma_out[(64 + lane) * 16 + i] = y[i];
