@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 (and 3, ragged split) gloo runs of the batch*head shard + all-gather
+(flash_attention_minitorch_amd/sharded.py).  The HIP kernels cannot run here, so the per-rank compute function is
+injected and backed by the CPU oracle -- only the partitioning / collective logic is under test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from flash_attention_minitorch_amd import sharded
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_fwd(q, k, v, causal):
+    o, L, _, _ = oracle.dense_attention_fw(q.numpy(), k.numpy(), v.numpy(), causal)
+    return torch.from_numpy(o.astype(np.float32)), torch.from_numpy(L.astype(np.float32))
+
+
+def _oracle_bwd(q, k, v, o, do, L, causal):
+    g = oracle.dense_attention_bw(q.numpy(), k.numpy(), v.numpy(), do.numpy(), causal)
+    return tuple(torch.from_numpy(a.astype(np.float32)) for a in g)
+
+
+def _worker(rank, world, port, bh_total, causal, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, d = 24, 16
+        rng = np.random.default_rng(123)   # every rank draws the full problem, then keeps its slice
+        full = [torch.from_numpy(rng.uniform(-1, 1, (bh_total, N, d)).astype(np.float32)) for _ in range(4)]
+        b, e = sharded.shard_range(bh_total, rank, world)
+        q, k, v, do = (t[b:e].contiguous() for t in full)
+        o, L = sharded.sharded_flash_attn2_fwd(q, k, v, bh_total, causal, compute_fn=_oracle_fwd)
+        o_loc, L_loc = sharded.sharded_flash_attn2_fwd(q, k, v, bh_total, causal, gather=False, compute_fn=_oracle_fwd)
+        dq, dk, dv = sharded.sharded_flash_attn2_bwd(q, k, v, o_loc, do, L_loc, bh_total, causal,
+                                                      compute_fn=_oracle_bwd)
+        assert o.shape == (bh_total, N, d) and L.shape == (bh_total, N)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), o=o.numpy(), L=L.numpy(), dq=dq.numpy(), dk=dk.numpy(),
+                 dv=dv.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bh_total,causal", [(2, 6, False), (2, 6, True), (3, 7, False)])
+def test_shard_and_gather_matches_single_process(tmp_path, world, bh_total, causal):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, bh_total, causal, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    q, k, v, do = (rng.uniform(-1, 1, (bh_total, 24, 16)).astype(np.float32) for _ in range(4))
+    o, L, _, _ = oracle.dense_attention_fw(q, k, v, causal)
+    dq, dk, dv = oracle.dense_attention_bw(q, k, v, do, causal)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for name, ref in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
+            assert np.max(np.abs(got[name] - ref)) < 1e-5, (r, name)
+
+
+def test_shard_bounds_are_contiguous_and_balanced():
+    for total in (0, 1, 7, 64, 2048):
+        for world in (1, 2, 3, 8):
+            b = sharded.shard_bounds(total, world)
+            assert b[0][0] == 0 and b[-1][1] == total
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in b]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharded.shard_range(2048, 3, 8) == (768, 1024)     # BASELINE.json configs[4]: 256 (b,h) per GPU
+    with pytest.raises(ValueError):
+        sharded.shard_bounds(4, 0)
