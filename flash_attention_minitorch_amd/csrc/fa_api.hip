@@ -33,25 +33,47 @@ int set_err(int code, const char* what, hipError_t e = hipSuccess) {
 inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
 inline int d_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
 
-template <typename T, int D>
-int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
-               int causal, int variant, float tau, hipStream_t st) {
-  constexpr int BN = sizeof(T) == 2 ? 64 : 32;
+int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fa_mi355x_set_tuning(): [0] dK/dV geometry, [1] fwd, [2] dQ tile
+
+template <typename T, int D, int BN, int WPE>
+int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
+                   int causal, int variant, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
-  hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+  hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
                      (const T*)v, out, l, m, N, nqb, batch, causal, variant, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
 
-int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0]: dK/dV geometry (0 = default, 1 = 4 waves x 64 keys, 2 = 8 waves x 32 keys)
+template <typename T, int D>
+int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
+               int causal, int variant, float tau, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    // 4 waves per SIMD (<= 128 VGPRs, 20 B/lane of scratch outside the loop): 2048 workgroups at the metric shape
+    // fill the chip in exactly two rounds instead of 2.67 (measured +2 %)
+    if (g_tuning[1] == 1) return fwd_launch_cfg<T, D, 64, 1>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
+    return fwd_launch_cfg<T, D, 64, 4>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
+  } else {
+    return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
+  }
+}
 
-template <typename T, int D, int KPW, int NW>
+template <typename T, int D, int KPW, int NW, int QS>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                 float* dk, float* dv, int batch, int N, int causal, float tau, hipStream_t st) {
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
-  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
+  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
                      (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, causal, tau);
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
+template <typename T, int D, int BN>
+int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
+              float* dq, int batch, int N, int causal, float tau, hipStream_t st) {
+  const int nqb = (N + 127) / 128;
+  hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+                     (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, causal, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
@@ -60,7 +82,6 @@ template <typename T, int D>
 int bwd_launch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
                float* dv, const float* l, const float* m, float* ws, int batch, int N, int causal, int variant,
                float tau, int stages, hipStream_t st) {
-  constexpr int BN = sizeof(T) == 2 ? 64 : 32;
   const long rows = (long)batch * N;
   float* nlc = ws;
   float* delta = ws + rows;
@@ -73,20 +94,37 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
   if (stages & FA_BWD_STAGE_DKDV) {
     int rc;
     if constexpr (sizeof(T) == 2 && D <= 64) {
+      // measured at B=8,H=8,N=4096,d=64 (ms, one device): 8 waves x 32 keys with 64-query stages 0.519, 128-query
+      // 0.511, 32-query 0.539; 4 waves x 32 keys (two workgroups per CU) 0.521; 4 waves x 64 keys 0.559
       if (g_tuning[0] == 1)
-        rc = dkdv_launch<T, D, 64, 4>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
-      else  // measured on MI355X at B=8,H=8,N=4096,d=64: 0.656 ms vs 0.806 ms (profiles/r01_variants.txt)
-        rc = dkdv_launch<T, D, 32, 8>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 64, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      else if (g_tuning[0] == 2)
+        rc = dkdv_launch<T, D, 32, 8, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      else
+        rc = dkdv_launch<T, D, 32, 8, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+    } else if constexpr (sizeof(T) == 2) {
+      if (g_tuning[0] == 1)
+        rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      else if (g_tuning[0] == 2)
+        rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      else
+        rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
     } else {
-      rc = dkdv_launch<T, D, 32, 4>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
     }
     if (rc) return rc;
   }
   if (stages & FA_BWD_STAGE_DQ) {
-    const int nqb = (N + 127) / 128;
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, causal, tau);
-    FA_HIP_TRY(hipGetLastError());
+    int rc;
+    if constexpr (sizeof(T) == 2 && D == 128) {
+      if (g_tuning[2] == 1)
+        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+      else
+        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+    } else {
+      rc = dq_launch<T, D, (sizeof(T) == 2 ? 64 : 32)>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+    }
+    if (rc) return rc;
   }
   return FA_OK;
 }

@@ -63,8 +63,8 @@ FA_DEV f32x16 zero16() {
 // ---------------------------------------------------------------------------------------------
 constexpr float MAX_DEFER = 6.0f;
 
-template <typename T, int D, int BN>
-__global__ void __launch_bounds__(256)
+template <typename T, int D, int BN, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
            float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, int causal, int aux_mode,
            float tau) {
@@ -273,16 +273,16 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 // the dK^T, dV^T accumulators of its KPW keys in registers while the workgroup sweeps 32-row query slices
 // (Q, dO tiles + their nlc, delta staged in LDS, double buffered).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int KPW, int NW>
+template <typename T, int D, int KPW, int NW, int QS>
 __global__ void __launch_bounds__(NW * 64)
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
                 float* __restrict__ dv, int N, int nkb, int BH, int causal, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
-  constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = NW * KPW, NT = NW * 64;
-  constexpr int TB = A::template tile_bytes<D>(32);
-  constexpr int BUF = 2 * TB + 256;  // Q tile, dO tile, 32 x nlc, 32 x delta
+  constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = NW * KPW, NT = NW * 64, NSUB = QS / 32;
+  constexpr int TB = A::template tile_bytes<D>(QS);
+  constexpr int BUF = 2 * TB + 8 * QS;  // Q tile, dO tile, QS x nlc, QS x -delta
   __shared__ __attribute__((aligned(16))) char smem_raw[2 * BUF];
   lds_char* smem = (lds_char*)smem_raw;
 
@@ -321,17 +321,17 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
-  const int nqi = (N + 31) / 32;
-  const int qi_begin = causal ? (kb0 / 32) : 0;  // query slices entirely above the key block are fully masked
-  TileStager<T, D, 32, NT> sq, sdo;
+  const int nqi = (N + QS - 1) / QS;
+  const int qi_begin = causal ? (kb0 / QS) : 0;  // query slices entirely above the key block are fully masked
+  TileStager<T, D, QS, NT> sq, sdo;
   sq.init(tid);
   sdo.init(tid);
   float st_nl = 0.f, st_de = 0.f;
   auto stage_load = [&](int qi) {
-    sq.load(qrs, qi * 32);
-    sdo.load(dors, qi * 32);
-    if (tid < 32) {
-      const int row = qi * 32 + tid;
+    sq.load(qrs, qi * QS);
+    sdo.load(dors, qi * QS);
+    if (tid < QS) {
+      const int row = qi * QS + tid;
       st_nl = row < N ? nlg[row] : 0.f;
       st_de = row < N ? deg[row] : 0.f;
     }
@@ -339,9 +339,9 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   auto stage_store = [&](lds_char* b) {
     sq.store(b);
     sdo.store(b + TB);
-    if (tid < 32) {
+    if (tid < QS) {
       *FA_LDS(float, b + 2 * TB + 4 * tid) = st_nl;
-      *FA_LDS(float, b + 2 * TB + 128 + 4 * tid) = st_de;
+      *FA_LDS(float, b + 2 * TB + 4 * QS + 4 * tid) = st_de;
     }
   };
   if (qi_begin < nqi) {
@@ -357,74 +357,77 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     lds_char* buf = smem + PAR * BUF;
     lds_char* tq = buf;
     lds_char* tdo = buf + TB;
-    const int qi0 = qi * 32;
-    const bool active = (kw0 < N) && (!causal || qi0 + 31 >= kw0);  // wave-uniform
-    if (active) {
-      // register i of lane half h is query qi0 + acc_row(i, h): its nlc / -delta come from LDS (broadcast reads);
-      // -delta enters the dP tile as the accumulator input of its first MFMA
-      f32x16 nl16, nd16;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 a = *FA_LDS(f32x4, buf + 2 * TB + 16 * h + 32 * g);
-        const f32x4 b = *FA_LDS(f32x4, buf + 2 * TB + 128 + 16 * h + 32 * g);
+    for (int sub = 0; sub < NSUB; ++sub) {
+      const int qi0 = qi * QS + 32 * sub;
+      const bool active = (kw0 < N) && (qi0 < N) && (!causal || qi0 + 31 >= kw0);  // wave-uniform
+      if (active) {
+        // register i of lane half h is query qi0 + acc_row(i, h): its nlc / -delta come from LDS (broadcast reads);
+        // -delta enters the dP tile as the accumulator input of its first MFMA
+        f32x16 nl16, nd16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          nl16[4 * g + j] = a[j];
-          nd16[4 * g + j] = b[j];
-        }
-      }
-      f32x16 s[KT], dp[KT];
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 a = *FA_LDS(f32x4, buf + 2 * TB + 128 * sub + 16 * h + 32 * g);
+          const f32x4 b = *FA_LDS(f32x4, buf + 2 * TB + 4 * QS + 128 * sub + 16 * h + 32 * g);
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const frag aq = A::template row_frag<D>(tq, ra, 0, kc);
-        const frag ado = A::template row_frag<D>(tdo, ra, 0, kc);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          if (kc == 0) {   // -delta rides in as dP's accumulator input (exact); S starts from zero
-            A::mma_c(s[kt], aq, kf[kt][kc], zero16());
-            A::mma_c(dp[kt], ado, vf[kt][kc], nd16);
-          } else {
-            A::mma(s[kt], aq, kf[kt][kc]);
-            A::mma(dp[kt], ado, vf[kt][kc]);
+          for (int j = 0; j < 4; ++j) {
+            nl16[4 * g + j] = a[j];
+            nd16[4 * g + j] = b[j];
           }
         }
-      }
-      const bool need_mask = causal && (kw0 + KPW - 1 > qi0);  // wave-uniform
+        f32x16 s[KT], dp[KT];
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+        for (int kc = 0; kc < KC; ++kc) {
+          const frag aq = A::template row_frag<D>(tq, ra, 32 * sub, kc);
+          const frag ado = A::template row_frag<D>(tdo, ra, 32 * sub, kc);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nl16[i]));
-      if (need_mask) {   // diagonal slices only (scalar branch)
+          for (int kt = 0; kt < KT; ++kt) {
+            if (kc == 0) {   // -delta rides in as dP's accumulator input (exact); S starts from zero
+              A::mma_c(s[kt], aq, kf[kt][kc], zero16());
+              A::mma_c(dp[kt], ado, vf[kt][kc], nd16);
+            } else {
+              A::mma(s[kt], aq, kf[kt][kc]);
+              A::mma(dp[kt], ado, vf[kt][kc]);
+            }
+          }
+        }
+        const bool need_mask = causal && (kw0 + KPW - 1 > qi0);  // wave-uniform
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (kw0 + 32 * kt + r > qi0 + acc_row(i, h)) s[kt][i] = 0.f;
-      }
+          for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nl16[i]));
+        if (need_mask) {   // diagonal slices only (scalar branch)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+          for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dp[kt][i] = s[kt][i] * dp[kt][i];
-      frag pf[KT][2], dsf[KT][2];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          pf[kt][s2] = A::pack(s[kt], s2);
-          dsf[kt][s2] = A::pack(dp[kt], s2);
+            for (int i = 0; i < 16; ++i)
+              if (kw0 + 32 * kt + r > qi0 + acc_row(i, h)) s[kt][i] = 0.f;
         }
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const frag adoT = A::template tr_frag<D>(tdo, ta, 16 * s2, dt);
-          const frag aqT = A::template tr_frag<D>(tq, ta, 16 * s2, dt);
+          for (int i = 0; i < 16; ++i) dp[kt][i] = s[kt][i] * dp[kt][i];
+        frag pf[KT][2], dsf[KT][2];
 #pragma unroll
-          for (int kt = 0; kt < KT; ++kt) {
-            A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
-            A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            pf[kt][s2] = A::pack(s[kt], s2);
+            dsf[kt][s2] = A::pack(dp[kt], s2);
           }
-        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
+            const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
+              A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
+            }
+          }
+      }
     }
     if (more) stage_store(smem + (PAR ^ 1) * BUF);
     __syncthreads();

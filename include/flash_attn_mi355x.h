@@ -103,8 +103,9 @@ const char* fa_mi355x_last_error(void);
 /* Library version, e.g. "flash_attn_mi355x 0.1 gfx950". */
 const char* fa_mi355x_version(void);
 
-/* Tuning hook (benchmarks only; results never depend on it).  key 0: dK/dV kernel geometry for bf16 d <= 64
- * (0 default, 1 = 4 waves x 64 keys, 2 = 8 waves x 32 keys per workgroup). */
+/* Tuning hook (in-process A/B benchmarks only; every setting computes the same function).
+ * key 0: dK/dV kernel geometry (0 default; 1, 2 alternatives), key 1: forward occupancy variant (bf16 d=64),
+ * key 2: dQ tile (bf16 d=128: 0 = 32-key tiles, 1 = 64-key tiles). */
 int fa_mi355x_set_tuning(int key, int value);
 
 /* Test hook: dumps what the MFMA operand readers see for a [64][d] tile (tests/test_gpu_layout.py).
