@@ -58,11 +58,11 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
   }
 }
 
-template <typename T, int D, int KPW, int NW, int QS>
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                 float* dk, float* dv, int batch, int N, int causal, float tau, hipStream_t st) {
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
-  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
+  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
                      (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, causal, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
@@ -94,14 +94,17 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
   if (stages & FA_BWD_STAGE_DKDV) {
     int rc;
     if constexpr (sizeof(T) == 2 && D <= 64) {
-      // measured at B=8,H=8,N=4096,d=64 (ms, one device): 8 waves x 32 keys with 64-query stages 0.519, 128-query
-      // 0.511, 32-query 0.539; 4 waves x 32 keys (two workgroups per CU) 0.521; 4 waves x 64 keys 0.559
+      // measured at B=8,H=8,N=4096,d=64 (ms, one device, profiles/README.md): 8 waves x 32 keys, 128-query stages,
+      // software-pipelined sub-slices 0.505; not pipelined 0.514; 64-query stages 0.519; 256-query 0.525;
+      // 4 waves x 32 keys (two workgroups per CU) 0.521; 4 waves x 64 keys (one wave per SIMD) 0.559
       if (g_tuning[0] == 1)
-        rc = dkdv_launch<T, D, 64, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 8, 128, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
       else if (g_tuning[0] == 2)
-        rc = dkdv_launch<T, D, 32, 8, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      else if (g_tuning[0] == 9)   // diagnostic build with phase stamps (never timed)
+        rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
       else
-        rc = dkdv_launch<T, D, 32, 8, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {
       if (g_tuning[0] == 1)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
@@ -224,6 +227,14 @@ extern "C" {
 
 const char* fa_mi355x_last_error(void) { return g_err; }
 const char* fa_mi355x_version(void) { return "flash_attn_mi355x 0.2 gfx950"; }
+
+int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n) {
+  g_err[0] = 0;
+  if (!host_out || n <= 0 || n > 8 * 8192) return set_err(FA_ERR_BAD_ARG, "bad debug buffer");
+  FA_HIP_TRY(hipDeviceSynchronize());
+  FA_HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fa::g_phase_cycles), (size_t)n * sizeof(unsigned long long)));
+  return FA_OK;
+}
 
 int fa_mi355x_set_tuning(int key, int value) {
   if (key < 0 || key >= 8) return set_err(FA_ERR_BAD_ARG, "unknown tuning key");

@@ -34,6 +34,17 @@ constexpr int AUX_FA2 = 2;  // l = logsumexp, m untouched                  (src/
 
 template <int V> using ic = std::integral_constant<int, V>;
 
+// Diagnostic builds only (MODE == 9 instantiation of the dK/dV kernel): per-wave cycle totals per loop phase,
+// written to a buffer of their own that no other code reads.  The real kernels execute no stamp.
+__device__ unsigned long long g_phase_cycles[8 * 8192];
+FA_DEV unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
 template <typename T> FA_DEV typename Atom<T>::frag load_frag_buf(rsrc_t rs, int byte_off);
 template <> FA_DEV bf16x8 load_frag_buf<bf16_t>(rsrc_t rs, int byte_off) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
@@ -273,7 +284,7 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 // the dK^T, dV^T accumulators of its KPW keys in registers while the workgroup sweeps 32-row query slices
 // (Q, dO tiles + their nlc, delta staged in LDS, double buffered).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int KPW, int NW, int QS>
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 __global__ void __launch_bounds__(NW * 64)
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
@@ -350,13 +361,97 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   }
   __syncthreads();
 
+  constexpr bool DIAG = MODE == 9;
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
   auto slice = [&](auto par, int qi) {
     constexpr int PAR = decltype(par)::value;
     const bool more = qi + 1 < nqi;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if constexpr (DIAG) t0 = stamp();
     if (more) stage_load(qi + 1);
+    if constexpr (DIAG) { t1 = stamp(); ph[0] += t1 - t0; }
     lds_char* buf = smem + PAR * BUF;
     lds_char* tq = buf;
     lds_char* tdo = buf + TB;
+    // ---- software-pipelined fast path (stage fully unmasked): S, dP of sub-slice i+1 are issued before the
+    // exp / mul / pack work of sub-slice i, so one wave has independent MFMA and VALU streams to interleave.
+    constexpr bool PIPE = MODE == 0 && NSUB == 4 && D <= 64;   // (needs ~250 VGPRs at d = 64; not for d = 128)
+    const bool fast = PIPE && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
+    if (fast) {
+      auto mfma1 = [&](auto subc, f32x16(&s)[KT], f32x16(&dp)[KT], f32x16& nl16) {
+        constexpr int sub = decltype(subc)::value;
+        f32x16 nd16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 a = *FA_LDS(f32x4, buf + 2 * TB + 128 * sub + 16 * h + 32 * g);
+          const f32x4 b = *FA_LDS(f32x4, buf + 2 * TB + 4 * QS + 128 * sub + 16 * h + 32 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            nl16[4 * g + j] = a[j];
+            nd16[4 * g + j] = b[j];
+          }
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const frag aq = A::template row_frag<D>(tq, ra, 32 * sub, kc);
+          const frag ado = A::template row_frag<D>(tdo, ra, 32 * sub, kc);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            if (kc == 0) {
+              A::mma_c(s[kt], aq, kf[kt][kc], zero16());
+              A::mma_c(dp[kt], ado, vf[kt][kc], nd16);
+            } else {
+              A::mma(s[kt], aq, kf[kt][kc]);
+              A::mma(dp[kt], ado, vf[kt][kc]);
+            }
+          }
+        }
+      };
+      auto valu = [&](f32x16(&s)[KT], f32x16(&dp)[KT], const f32x16& nl16, frag(&pf)[KT][2], frag(&dsf)[KT][2]) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nl16[i]));
+            dp[kt][i] = s[kt][i] * dp[kt][i];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            pf[kt][s2] = A::pack(s[kt], s2);
+            dsf[kt][s2] = A::pack(dp[kt], s2);
+          }
+        }
+      };
+      auto mfma2 = [&](auto subc, const frag(&pf)[KT][2], const frag(&dsf)[KT][2]) {
+        constexpr int sub = decltype(subc)::value;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
+            const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
+              A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
+            }
+          }
+      };
+      f32x16 sA[KT], dpA[KT], sB[KT], dpB[KT], nlA, nlB;
+      frag pf[KT][2], dsf[KT][2];
+      mfma1(ic<0>{}, sA, dpA, nlA);
+      mfma1(ic<1>{}, sB, dpB, nlB);
+      valu(sA, dpA, nlA, pf, dsf);
+      mfma2(ic<0>{}, pf, dsf);
+      mfma1(ic<2>{}, sA, dpA, nlA);
+      valu(sB, dpB, nlB, pf, dsf);
+      mfma2(ic<1>{}, pf, dsf);
+      mfma1(ic<3>{}, sB, dpB, nlB);
+      valu(sA, dpA, nlA, pf, dsf);
+      mfma2(ic<2>{}, pf, dsf);
+      valu(sB, dpB, nlB, pf, dsf);
+      mfma2(ic<3>{}, pf, dsf);
+    } else
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
       const int qi0 = qi * QS + 32 * sub;
@@ -364,6 +459,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       if (active) {
         // register i of lane half h is query qi0 + acc_row(i, h): its nlc / -delta come from LDS (broadcast reads);
         // -delta enters the dP tile as the accumulator input of its first MFMA
+        if constexpr (DIAG) t1 = stamp();
         f32x16 nl16, nd16;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -392,6 +488,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           }
         }
         const bool need_mask = causal && (kw0 + KPW - 1 > qi0);  // wave-uniform
+        if constexpr (DIAG) { t2 = stamp(); ph[1] += t2 - t1; }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -415,6 +512,19 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
             pf[kt][s2] = A::pack(s[kt], s2);
             dsf[kt][s2] = A::pack(dp[kt], s2);
           }
+        if constexpr (DIAG) {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {   // pin the VALU phase in front of the stamp
+                asm volatile("" ::"v"(__builtin_bit_cast(u32x4, pf[kt][s2])[j]));
+                asm volatile("" ::"v"(__builtin_bit_cast(u32x4, dsf[kt][s2])[j]));
+              }
+          t3 = stamp();
+          ph[2] += t3 - t2;
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -427,10 +537,14 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
               A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
             }
           }
+        if constexpr (DIAG) { t0 = stamp(); ph[3] += t0 - t3; }
       }
     }
+    if constexpr (DIAG) t0 = stamp();
     if (more) stage_store(smem + (PAR ^ 1) * BUF);
+    if constexpr (DIAG) { t1 = stamp(); ph[4] += t1 - t0; }
     __syncthreads();
+    if constexpr (DIAG) { t2 = stamp(); ph[5] += t2 - t1; }
   };
   int qi = qi_begin;
   for (; qi + 1 < nqi; qi += 2) {
@@ -439,6 +553,11 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   }
   if (qi < nqi) slice(ic<0>{}, qi);
 
+  if constexpr (DIAG) {
+    const int slot = blockIdx.x * NW + w;
+    if (slot < 8192 && lane == 0)
+      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
+  }
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     const int key = kw0 + 32 * kt + r;

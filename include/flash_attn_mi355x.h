@@ -108,6 +108,10 @@ const char* fa_mi355x_version(void);
  * key 2: dQ tile (bf16 d=128: 0 = 32-key tiles, 1 = 64-key tiles). */
 int fa_mi355x_set_tuning(int key, int value);
 
+/* Profiling hook: per-wave cycle totals per loop phase written by the DIAGNOSTIC dK/dV build (tuning key 0 = 9);
+ * copies the first n counters (8 per wave slot) to host memory. */
+int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n);
+
 /* Test hook: dumps what the MFMA operand readers see for a [64][d] tile (tests/test_gpu_layout.py).
  * All pointers are device pointers; returns a status code. */
 int fa_mi355x_probe(const void* tile, const void* b, float* row_out, float* tr_out, float* mma_out,
