@@ -94,6 +94,46 @@ def test_host_abi_causal_and_ones_grad(ops, golden_dir, name, fw, bw, conv):
     assert maxabs(dv[0], ref["dv"]) < TOL32
 
 
+# ---------------------------------------------------------------- the reference's own test shapes, full batch
+def test_reference_comb_test_shape(ops):
+    """kernel_tests/test_flashattn_comb.py:86-90: B=128, H=8, N=40, d=32, non-causal flash_attn + backward with
+    out_grad = ones (N is not a multiple of any tile size)."""
+    rng = np.random.default_rng(86)
+    shp = (128, 8, 40, 32)
+    q, k, v = (rand_u(rng, shp) for _ in range(3))
+    do = np.ones(shp, np.float32)
+    o, l, m = ops.flash_attn_fw(q, k, v, False)
+    dq, dk, dv, _ = ops.flash_attn_bw(q, k, v, o, do, l, m, False)
+    f = lambda a: a.reshape(1024, 40, -1)
+    heads = range(0, 1024, 17)
+    ref = oracle_heads(f(q), f(k), f(v), f(do), False, heads)
+    idx = list(heads)
+    assert maxabs(f(o)[idx], ref["o"]) < TOL32
+    assert maxabs(m.reshape(1024, 40)[idx], ref["m"]) < 1e-5
+    assert maxabs(f(dq)[idx], ref["dq"]) < TOL32
+    assert maxabs(f(dk)[idx], ref["dk"]) < TOL32
+    assert maxabs(f(dv)[idx], ref["dv"]) < TOL32
+
+
+def test_reference_odd_head_dim_shape(ops):
+    """kernel_tests/test_flashattn_2_fw.py:133-140: B=8, H=8, N=327, d=34 (FA-2 forward, causal); d is padded to 64
+    inside the host launcher, tau stays sqrt(1/34)."""
+    rng = np.random.default_rng(133)
+    shp = (8, 8, 327, 34)
+    q, k, v, do = (rand_u(rng, shp) for _ in range(4))
+    o, l, m = ops.flash_attn2_fw(q, k, v, True)
+    dq, dk, dv, _ = ops.flash_attn2_bw(q, k, v, o, do, l, m, True)
+    f = lambda a: a.reshape(64, 327, -1)
+    heads = [0, 9, 31, 63]
+    ref = oracle_heads(f(q), f(k), f(v), f(do), True, heads)
+    assert maxabs(f(o)[heads], ref["o"]) < TOL32
+    assert maxabs(l.reshape(64, 327)[heads], ref["L"]) < TOL32
+    assert np.all(m == -FLT_MAX)
+    assert maxabs(f(dq)[heads], ref["dq"]) < TOL32
+    assert maxabs(f(dk)[heads], ref["dk"]) < TOL32
+    assert maxabs(f(dv)[heads], ref["dv"]) < TOL32
+
+
 # ---------------------------------------------------------------- BASELINE.json configs[1], configs[2] (fp32, full size)
 def test_c1_fa1_forward_fp32_full(ops):
     rng = np.random.default_rng(1001)
