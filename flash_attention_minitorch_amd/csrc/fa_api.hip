@@ -48,14 +48,7 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
 template <typename T, int D>
 int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                int causal, int variant, float tau, hipStream_t st) {
-  if constexpr (sizeof(T) == 2 && D == 64) {
-    // 4 waves per SIMD (<= 128 VGPRs, 20 B/lane of scratch outside the loop): 2048 workgroups at the metric shape
-    // fill the chip in exactly two rounds instead of 2.67 (measured +2 %)
-    if (g_tuning[1] == 1) return fwd_launch_cfg<T, D, 64, 1>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
-    return fwd_launch_cfg<T, D, 64, 4>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
-  } else {
-    return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
-  }
+  return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
 }
 
 template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>

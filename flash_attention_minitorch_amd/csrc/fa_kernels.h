@@ -66,13 +66,13 @@ FA_DEV f32x16 zero16() {
 // Forward.  P = exp2(c*s - c*m_ref) with c = tau*log2(e) applied in fp32 (one fma per score: pre-scaling Q or K
 // in bf16 was measured to cost up to 3.7e-3 max-abs on O at small N -- the rounding is the same for every key of a
 // row, so it does not average out).  m_ref is a per-row REFERENCE, not the running maximum: it is only moved
-// (O, l rescaled) when a row maximum outgrows it by more than MAX_DEFER in log2 units, so P stays <= 2^MAX_DEFER,
-// which fp32 / bf16 hold at full relative precision, and the steady state has no rescale work at all.
+// (O, l rescaled) when some P of the row would exceed 2^6, which fp32 / bf16 hold at full relative precision; the
+// steady state computes neither a row maximum nor a rescale (time ~ MFMA + VALU on this chip: they barely co-issue).
 // Row sums stay on the VALU in fp32: summing the bf16-rounded P on the MFMA (ones . P^T) was measured 4 % faster
 // but puts P's 2^-9 quantisation into L = m + log(l), which the backward then exponentiates (dV error 2.7e-3 on
-// causal rows with few keys).  The MFMA form is kept behind MFMA_SUM for experiments.
+// causal rows with few keys).
 // ---------------------------------------------------------------------------------------------
-constexpr float MAX_DEFER = 6.0f;
+constexpr float MAX_DEFER_SUM = 64.0f;   // 2^6: bound on a lane's partial row sum (hence on every P) in the steady state
 
 template <typename T, int D, int BN, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
@@ -83,7 +83,6 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
   constexpr int TB = A::template tile_bytes<D>(BN);
-  constexpr bool MFMA_SUM = false;
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
@@ -109,9 +108,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   f32x16 acc_o[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc_o[dt] = zero16();
-  f32x16 acc_l = zero16();   // bf16 path: every register holds the row sum (ones . P^T)
   float m_ref = 0.f, nmc = 0.f, m_true = -INFINITY, l_run = 0.f;   // raw score units; nmc = -m_ref * c
-  const frag ones = A::ones();
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
@@ -140,57 +137,71 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     const bool active = !causal || kbase <= q0 + 31;  // wave-uniform
     if (active) {
       f32x16 s[KT];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        s[kt] = zero16();
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
-      }
       const bool need_mask = (kbase + BN > N) || (causal && kbase + BN - 1 > q0);  // wave-uniform
-      if (need_mask) {
+      auto scores = [&]() {   // S^T tile of this wave (raw units), masked
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          s[kt] = zero16();
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
+        }
+        if (need_mask) {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int key = kbase + 32 * kt + acc_row(i, h);
+              if (key >= N || (causal && key > qrow)) s[kt][i] = -INFINITY;
+            }
+        }
+      };
+      auto tile_max = [&]() {   // row maximum of this tile (raw score units)
+        float mx = s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt][i]);
+        return xhalf_max(mx);
+      };
+      auto exps = [&]() {       // s <- P = exp2(c*s - c*m_ref); returns this lane's partial row sum
+        float rowsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int key = kbase + 32 * kt + acc_row(i, h);
-            if (key >= N || (causal && key > qrow)) s[kt][i] = -INFINITY;
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nmc));
+            s[kt][i] = p;
+            rowsum += p;
           }
-      }
-      float mx = s[0][0];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt][i]);
-      mx = xhalf_max(mx);                      // row maximum of this tile (raw score units)
-      m_true = fmaxf(m_true, mx);
-      float alpha = 1.0f;
-      // move the reference when some row outgrew it (always on the first tile: m_ref = its row max)
-      if (FIRST || __any(__builtin_fmaf(mx, c, nmc) > MAX_DEFER)) {
-        const float delta = FIRST ? mx : fmaxf(mx - m_ref, 0.f);
-        if (!FIRST) {
+        return rowsum;
+      };
+      scores();
+      float rowsum, alpha = 1.0f;
+      if (FIRST) {                      // the first tile sets the reference to its row maximum
+        m_ref = tile_max();
+        m_true = m_ref;
+        nmc = -m_ref * c;
+        rowsum = exps();
+      } else {
+        if (aux_mode == AUX_FA1) m_true = fmaxf(m_true, tile_max());   // only FA-1 reports the true row maximum
+        // Steady state: no maximum at all.  P is computed against the current reference; a lane whose partial row
+        // sum stays under 2^MAX_DEFER cannot hold a P above it.  Otherwise (rare: some row outgrew its reference)
+        // the tile is redone the classic way: scores again, true maximum, reference moved, O and l rescaled.
+        rowsum = exps();
+        if (__any(!(rowsum < MAX_DEFER_SUM))) {
+          scores();
+          const float delta = fmaxf(tile_max() - m_ref, 0.f);
           alpha = __builtin_amdgcn_exp2f(-delta * c);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
-          if (MFMA_SUM) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc_l[i] *= alpha;
-          }
+          m_ref += delta;
+          nmc = -m_ref * c;
+          rowsum = exps();
         }
-        m_ref += delta;
-        nmc = -m_ref * c;
       }
-      float rowsum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nmc));
-          s[kt][i] = p;
-          if (!MFMA_SUM) rowsum += p;
-        }
-      if (!MFMA_SUM) l_run = l_run * alpha + rowsum;
+      l_run = l_run * alpha + rowsum;
       frag pf[KT][2];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
@@ -200,12 +211,10 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          if (MFMA_SUM) A::mma(acc_l, ones, pf[kt][s2]);
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt)
             A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pf[kt][s2]);
-        }
     }
     if (more) {
       sk.store(smem + (PAR ^ 1) * TB);
@@ -221,7 +230,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   }
   if (t < nt) tile(ic<1>{}, ic<0>{}, t);
 
-  const float l_tot = MFMA_SUM ? acc_l[0] : xhalf_sum(l_run);   // sum of exp2(s - m_ref)
+  const float l_tot = xhalf_sum(l_run);   // sum of exp2(c*(s - m_ref))
   const float inv = 1.0f / l_tot;
   if (qvalid) {
     float* orow = o + base + (size_t)qrow * D;
