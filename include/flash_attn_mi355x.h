@@ -104,8 +104,8 @@ const char* fa_mi355x_last_error(void);
 const char* fa_mi355x_version(void);
 
 /* Tuning hook (in-process A/B benchmarks only; every setting computes the same function).
- * key 0: dK/dV kernel geometry (0 default; 1, 2 alternatives), key 1: forward occupancy variant (bf16 d=64),
- * key 2: dQ tile (bf16 d=128: 0 = 32-key tiles, 1 = 64-key tiles). */
+ * key 0: dK/dV kernel (0 default: software-pipelined; 1 plain; 2 four waves x 64 keys; 9 diagnostic build with
+ * phase stamps), key 2: dQ tile (bf16: 0 = 32-key tiles, 1 = 64-key tiles).  Other keys are reserved. */
 int fa_mi355x_set_tuning(int key, int value);
 
 /* Profiling hook: per-wave cycle totals per loop phase written by the DIAGNOSTIC dK/dV build (tuning key 0 = 9);
