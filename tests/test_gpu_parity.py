@@ -227,6 +227,34 @@ def test_device_path_small_shapes(dev, dtype, d, N, causal):
         assert maxabs(to_np(dv), ref["dv"]) < tol
 
 
+def test_long_sequence(dev):
+    """N = 8192 against the oracle on one head, and N = 32768 through size-independent properties (no N^2 memory on
+    either side: the reference's only sequence-length limit is time)."""
+    import torch
+    errs, _, _ = _bf16_case(dev, 1, 2, 8192, 64, False, [1], 2001)
+    for nm, e in errs.items():
+        assert e < TOLBF, (nm, e)
+    errs, _, _ = _bf16_case(dev, 1, 2, 8192, 64, True, [0], 2002)
+    for nm, e in errs.items():
+        assert e < TOLBF_CAUSAL, (nm, e)
+    torch.manual_seed(1)
+    N = 32768
+    mk = lambda: ((torch.rand((2, N, 64), device="cuda") - 0.5) * 2).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    for causal in (False, True):
+        o1, L1, _ = dev.flash_attn_fwd(q, k, torch.ones_like(v), causal=causal)
+        assert (o1 - 1).abs().max().item() < (2e-3 if causal else 2e-4)   # causal: rows with 2-4 keys, bf16 P
+        o, L, _ = dev.flash_attn_fwd(q, k, v, causal=causal)
+        dq, dk, dv = dev.flash_attn_bwd(q, k, v, o, do, L, causal=causal)
+        for t in (o, L, dq, dk, dv):
+            assert torch.isfinite(t).all()
+        assert (dv.sum(dim=1) - do.float().sum(dim=1)).abs().max().item() < 0.2     # columns of P^T sum: sum_n dV = sum_n dO
+        lhs = (dq.double() * q.double()).sum(dim=(1, 2)); rhs = (dk.double() * k.double()).sum(dim=(1, 2))
+        assert (lhs - rhs).abs().max().item() < 5e-2
+        if not causal:   # L >= log(N) + min score, <= log(N) + max score
+            assert (L - float(np.log(N))).abs().max().item() < 1.5
+
+
 # ---------------------------------------------------------------- size-independent properties at full size
 def test_properties_at_metric_shape(dev):
     import torch
