@@ -33,6 +33,8 @@ FA_VARIANT_FA2 = 2
 FA_DTYPE_F32 = 0
 FA_DTYPE_BF16 = 1
 FA_OK = 0
+FA_LAYOUT_BHND = 0
+FA_LAYOUT_BNHD = 1
 
 _handles: dict = {}
 
@@ -78,6 +80,10 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_bwd.restype = _i
     h.fa_mi355x_bwd_stages.argtypes = [_vp] * 11 + [_i] * 7 + [_vp]
     h.fa_mi355x_bwd_stages.restype = _i
+    h.fa_mi355x_fwd_layout.argtypes = [_vp] * 6 + [_i] * 8 + [_vp]
+    h.fa_mi355x_fwd_layout.restype = _i
+    h.fa_mi355x_bwd_layout.argtypes = [_vp] * 11 + [_i] * 8 + [_vp]
+    h.fa_mi355x_bwd_layout.restype = _i
     h.fa_mi355x_bwd_workspace_bytes.argtypes = [_i, _i, _i]
     h.fa_mi355x_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.fa_mi355x_last_error.argtypes = []

@@ -37,51 +37,52 @@ int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fa_mi355x_set_tuning(): [0] dK/d
 
 template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
-                   int causal, int variant, float tau, hipStream_t st) {
+                   fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
   hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
-                     (const T*)v, out, l, m, N, nqb, batch, causal, variant, tau);
+                     (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
 
 template <typename T, int D>
 int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
-               int causal, int variant, float tau, hipStream_t st) {
-  return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, causal, variant, tau, st);
+               fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
+  return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, lay, causal, variant, tau,
+                                                             st);
 }
 
 template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-                float* dk, float* dv, int batch, int N, int causal, float tau, hipStream_t st) {
+                float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
   hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
-                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, causal, tau);
+                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
 
 template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-              float* dq, int batch, int N, int causal, float tau, hipStream_t st) {
+              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
   hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
-                     (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, causal, tau);
+                     (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
 
 template <typename T, int D>
 int bwd_launch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
-               float* dv, const float* l, const float* m, float* ws, int batch, int N, int causal, int variant,
-               float tau, int stages, hipStream_t st) {
+               float* dv, const float* l, const float* m, float* ws, int batch, int N, fa::Layout lay, int causal,
+               int variant, float tau, int stages, hipStream_t st) {
   const long rows = (long)batch * N;
   float* nlc = ws;
   float* delta = ws + rows;
   constexpr int RPB = 256 / (D / 8);
   if (stages & FA_BWD_STAGE_PREP) {
     hipLaunchKernelGGL((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
-                       (const T*)dout, l, m, nlc, delta, rows, variant);
+                       (const T*)dout, l, m, nlc, delta, rows, N, lay, variant);
     FA_HIP_TRY(hipGetLastError());
   }
   if (stages & FA_BWD_STAGE_DKDV) {
@@ -91,22 +92,22 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       // software-pipelined sub-slices 0.505; not pipelined 0.514; 64-query stages 0.519; 256-query 0.525;
       // 4 waves x 32 keys (two workgroups per CU) 0.521; 4 waves x 64 keys (one wave per SIMD) 0.559
       if (g_tuning[0] == 1)
-        rc = dkdv_launch<T, D, 32, 8, 128, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 8, 128, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 2)
-        rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 9)   // diagnostic build with phase stamps (never timed)
-        rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else
-        rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {
       if (g_tuning[0] == 1)
-        rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 2)
-        rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else
-        rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else {
-      rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, causal, tau, st);
+      rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     }
     if (rc) return rc;
   }
@@ -114,16 +115,16 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     int rc;
     if constexpr (sizeof(T) == 2 && D == 128) {
       if (g_tuning[2] == 1)
-        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else
-        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {   // d <= 64: 32-key tiles run 3 waves/SIMD (154 VGPRs), measured 2 % faster
       if (g_tuning[2] == 1)
-        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else
-        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
     } else {
-      rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, causal, tau, st);
+      rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
     }
     if (rc) return rc;
   }
@@ -145,17 +146,20 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 
 // tau uses the caller's d even when the rows are zero-padded to dp columns (zero columns of Q/K add
 // nothing to the scores; zero columns of V produce zero output columns that are dropped).
+fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0}; }
+fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp}; }
+
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
-                 int dp, int causal, int variant, int dtype, hipStream_t st) {
+                 int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st) {
   const float tau = sqrtf(1.0f / (float)d);
-  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, causal, variant, tau, st);
+  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st);
 }
 
 int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
-                 float* dv, const float* l, const float* m, float* ws, int batch, int N, int d, int dp, int causal,
-                 int variant, int dtype, int stages, hipStream_t st) {
+                 float* dv, const float* l, const float* m, float* ws, int batch, int N, int d, int dp, fa::Layout lay,
+                 int causal, int variant, int dtype, int stages, hipStream_t st) {
   const float tau = sqrtf(1.0f / (float)d);
-  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, causal, variant, tau, stages, st);
+  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, lay, causal, variant, tau, stages, st);
 }
 
 int check_common(int batch, int N, int d, int variant, int dtype) {
@@ -247,7 +251,39 @@ int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float
   if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m))
     return set_err(FA_ERR_BAD_ARG, "null pointer argument");
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
-  return fwd_dispatch(q, k, v, out, l, m, batch, N, d, d, causal ? 1 : 0, variant, dtype, (hipStream_t)stream);
+  return fwd_dispatch(q, k, v, out, l, m, batch, N, d, d, bhnd(N, d), causal ? 1 : 0, variant, dtype,
+                      (hipStream_t)stream);
+}
+
+int fa_mi355x_fwd_layout(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H,
+                         int N, int d, int layout, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  return fwd_dispatch(q, k, v, out, l, m, B * H, N, d, d, lay, causal ? 1 : 0, variant, dtype, (hipStream_t)stream);
+}
+
+int fa_mi355x_bwd_layout(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                         float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m, void* workspace,
+                         int B, int H, int N, int d, int layout, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
+                      causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream);
 }
 
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d) {
@@ -274,7 +310,7 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
     return set_err(FA_ERR_BAD_ARG, "null pointer argument");
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
   return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, batch, N, d, d,
-                      causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream);
+                      bhnd(N, d), causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream);
 }
 
 void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* out, float* l, float* m, int batch,
@@ -299,7 +335,8 @@ void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* 
   h2d_rows(dq_, q, rows, d, dp, st);
   h2d_rows(dk_, k, rows, d, dp, st);
   h2d_rows(dv_, v, rows, d, dp, st);
-  if (fwd_dispatch(dq_, dk_, dv_, do_, dl_, dm_, batch, N, d, dp, causal_mask ? 1 : 0, variant, FA_DTYPE_F32, st))
+  if (fwd_dispatch(dq_, dk_, dv_, do_, dl_, dm_, batch, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0, variant,
+                   FA_DTYPE_F32, st))
     die(g_err, hipSuccess);
   d2h_rows(out, do_, rows, d, dp, st);
   FA_HOST_TRY(hipMemcpyAsync(l, dl_, rows * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -341,8 +378,8 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
   h2d_rows(bdo, out_grad, rows, d, dp, st);
   FA_HOST_TRY(hipMemcpyAsync(bl, l, rows * sizeof(float), hipMemcpyHostToDevice, st));
   FA_HOST_TRY(hipMemcpyAsync(bm, m, rows * sizeof(float), hipMemcpyHostToDevice, st));
-  if (bwd_dispatch(bq, bk, bv, bo, bdo, bdq, bdk, bdv, bl, bm, ws, batch, N, d, dp, causal_mask ? 1 : 0, variant,
-                   FA_DTYPE_F32, FA_BWD_STAGE_ALL, st))
+  if (bwd_dispatch(bq, bk, bv, bo, bdo, bdq, bdk, bdv, bl, bm, ws, batch, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0,
+                   variant, FA_DTYPE_F32, FA_BWD_STAGE_ALL, st))
     die(g_err, hipSuccess);
   d2h_rows(q_grad, bdq, rows, d, dp, st);
   d2h_rows(k_grad, bdk, rows, d, dp, st);

@@ -203,8 +203,10 @@ template <typename T, int D, int ROWS, int NT> struct TileStager {
   u32x4 regs[PER];
   int voff;       // byte offset of this thread's first chunk inside the global tile
   int lds_off;    // byte offset of this thread's first chunk inside the LDS image
+  int ldb;        // bytes between consecutive rows in global memory (row stride: D elements, or H*D for [B][N][H][d])
   bool live;      // this thread has a chunk at all (NCH < NT)
-  FA_DEV void init(int tid) {
+  FA_DEV void init(int tid, int ld) {
+    ldb = ld * (int)sizeof(T);
     int row = tid / CPR, ch = tid % CPR;
     if constexpr (sizeof(T) == 2 && CPR >= 8) {
       // bf16 image: a ds_write_b128 lane group (8 consecutive lanes) must cover 128 distinct bytes mod 128:
@@ -213,19 +215,19 @@ template <typename T, int D, int ROWS, int NT> struct TileStager {
       row = 2 * (g / (CPR / 4)) + ((tid >> 2) & 1);
       ch = 4 * (g % (CPR / 4)) + (tid & 3);
     }
-    voff = (row * D) * (int)sizeof(T) + ch * 16;
+    voff = row * ldb + ch * 16;
     lds_off = Atom<T>::template off<D>(row, ch);
     live = (NCH >= NT) || tid < NCH;
   }
   // row0 (wave-uniform): first row of the tile inside the matrix the resource covers
   FA_DEV void load(rsrc_t rs, int row0) {
-    const int soff = row0 * D * (int)sizeof(T);
+    const int soff = row0 * ldb;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (NCH % NT == 0 || live)
         v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                          rs, voff + i * RSTEP * D * (int)sizeof(T), soff, 0));
+                                          rs, voff + i * RSTEP * ldb, soff, 0));
       regs[i] = v;
     }
   }
@@ -236,6 +238,20 @@ template <typename T, int D, int ROWS, int NT> struct TileStager {
         *FA_LDS(u32x4, tile + lds_off + Atom<T>::template off<D>(i * RSTEP, 0)) = regs[i];
   }
 };
+
+// Where one (batch*head) matrix lives: element (n, :) of head bh is at head_base(bh) + n * ld.
+// [BH][N][d] (the reference layout): H = 1, ld = d, bstride = N*d, hstride = 0.
+// [B][N][H][d] (what the projection writes before minitorch's permute + contiguous, modules_transfomer.py:67-89):
+// H = heads, ld = H*d, bstride = N*H*d, hstride = d.
+struct Layout {
+  int H;
+  int ld;
+  long bstride;
+  long hstride;
+};
+FA_DEV size_t head_base(const Layout& L, int bh) {
+  return (size_t)(bh / L.H) * (size_t)L.bstride + (size_t)(bh % L.H) * (size_t)L.hstride;
+}
 
 // Workgroup id -> (batch*head, block) with every block of one (batch*head) on the same XCD
 // (blocks b and b+8 share an XCD's L2 under round-robin dispatch; speed only, never correctness).

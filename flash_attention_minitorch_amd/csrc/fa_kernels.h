@@ -77,8 +77,8 @@ constexpr float MAX_DEFER_SUM = 64.0f;   // 2^6: bound on a lane's partial row s
 template <typename T, int D, int BN, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
-           float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, int causal, int aux_mode,
-           float tau) {
+           float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, Layout lay, int causal,
+           int aux_mode, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
@@ -93,8 +93,9 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   if (causal) qb = nqb - 1 - qb;  // heaviest query blocks first
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
-  const size_t base = (size_t)bh * N * D;
-  const uint32_t mat_bytes = (uint32_t)N * D * (uint32_t)sizeof(T);
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;   // elements between consecutive rows
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const rsrc_t krs = make_rsrc(k + base, mat_bytes);
   const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
@@ -103,7 +104,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   frag qf[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc)
-    qf[kc] = load_frag_buf<T>(qrs, (qrow * D + 16 * kc + 8 * h) * (int)sizeof(T));
+    qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
 
   f32x16 acc_o[DT];
 #pragma unroll
@@ -115,8 +116,8 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   const int kmax = causal ? min(N, qb * 128 + 128) : N;
   const int nt = (kmax + BN - 1) / BN;
   TileStager<T, D, BN, 256> sk, sv;
-  sk.init(tid);
-  sv.init(tid);
+  sk.init(tid, ld);
+  sv.init(tid, ld);
   sk.load(krs, 0);
   sv.load(vrs, 0);
   sk.store(smem);
@@ -233,7 +234,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   const float l_tot = xhalf_sum(l_run);   // sum of exp2(c*(s - m_ref))
   const float inv = 1.0f / l_tot;
   if (qvalid) {
-    float* orow = o + base + (size_t)qrow * D;
+    float* orow = o + base + (size_t)qrow * ld;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -263,8 +264,8 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 template <typename T, int D>
 __global__ void __launch_bounds__(256)
 bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ l,
-                const float* __restrict__ m, float* __restrict__ nlc, float* __restrict__ ndelta, long rows,
-                int aux_mode) {
+                const float* __restrict__ m, float* __restrict__ nlc, float* __restrict__ ndelta, long rows, int N,
+                Layout lay, int aux_mode) {
   constexpr int LPR = D / 8;  // lanes per row, 8 elements each
   constexpr int RPB = 256 / LPR;
   const int tid = threadIdx.x;
@@ -272,8 +273,9 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
   const int part = tid % LPR;
   float sum = 0.f;
   if (row < rows) {
-    const float* op = o + row * D + part * 8;
-    const T* dp = dout + row * D + part * 8;
+    const size_t off = head_base(lay, (int)(row / N)) + (size_t)(row % N) * lay.ld + part * 8;
+    const float* op = o + off;
+    const T* dp = dout + off;
     f32x4 o0 = *reinterpret_cast<const f32x4*>(op), o1 = *reinterpret_cast<const f32x4*>(op + 4);
     typename Atom<T>::frag df = Atom<T>::load_global(dp);
 #pragma unroll
@@ -297,7 +299,7 @@ template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 __global__ void __launch_bounds__(NW * 64)
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
-                float* __restrict__ dv, int N, int nkb, int BH, int causal, float tau) {
+                float* __restrict__ dv, int N, int nkb, int BH, Layout lay, int causal, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = NW * KPW, NT = NW * 64, NSUB = QS / 32;
@@ -311,8 +313,9 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   int bh, kb;
   map_block(blockIdx.x, BH, nkb, bh, kb);
   const int kb0 = kb * BK, kw0 = kb0 + w * KPW;
-  const size_t base = (size_t)bh * N * D;
-  const uint32_t mat_bytes = (uint32_t)N * D * (uint32_t)sizeof(T);
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;   // elements between consecutive rows
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
   const rsrc_t krs = make_rsrc(k + base, mat_bytes);
@@ -326,7 +329,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const int off = ((kw0 + 32 * kt + r) * D + 16 * kc + 8 * h) * (int)sizeof(T);  // rows >= N read as zero
+      const int off = ((kw0 + 32 * kt + r) * ld + 16 * kc + 8 * h) * (int)sizeof(T);  // rows >= N read as zero
       kf[kt][kc] = load_frag_buf<T>(krs, off);
       vf[kt][kc] = load_frag_buf<T>(vrs, off);
     }
@@ -344,8 +347,8 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   const int nqi = (N + QS - 1) / QS;
   const int qi_begin = causal ? (kb0 / QS) : 0;  // query slices entirely above the key block are fully masked
   TileStager<T, D, QS, NT> sq, sdo;
-  sq.init(tid);
-  sdo.init(tid);
+  sq.init(tid, ld);
+  sdo.init(tid, ld);
   float st_nl = 0.f, st_de = 0.f;
   auto stage_load = [&](int qi) {
     sq.load(qrs, qi * QS);
@@ -571,8 +574,8 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   for (int kt = 0; kt < KT; ++kt) {
     const int key = kw0 + 32 * kt + r;
     if (key < N) {
-      float* dkrow = dk + base + (size_t)key * D;
-      float* dvrow = dv + base + (size_t)key * D;
+      float* dkrow = dk + base + (size_t)key * ld;
+      float* dvrow = dv + base + (size_t)key * ld;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -595,7 +598,7 @@ template <typename T, int D, int BN>
 __global__ void __launch_bounds__(256)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
-              int BH, int causal, float tau) {
+              int BH, Layout lay, int causal, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
@@ -610,8 +613,9 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   if (causal) qb = nqb - 1 - qb;
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
-  const size_t base = (size_t)bh * N * D;
-  const uint32_t mat_bytes = (uint32_t)N * D * (uint32_t)sizeof(T);
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;   // elements between consecutive rows
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
   const rsrc_t krs = make_rsrc(k + base, mat_bytes);
@@ -621,7 +625,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   frag qf[KC], dof[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
-    const int off = (qrow * D + 16 * kc + 8 * h) * (int)sizeof(T);
+    const int off = (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T);
     qf[kc] = load_frag_buf<T>(qrs, off);
     dof[kc] = load_frag_buf<T>(dors, off);
   }
@@ -641,8 +645,8 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   const int kmax = causal ? min(N, qb * 128 + 128) : N;
   const int nt = (kmax + BN - 1) / BN;
   TileStager<T, D, BN, 256> sk, sv;
-  sk.init(tid);
-  sv.init(tid);
+  sk.init(tid, ld);
+  sv.init(tid, ld);
   sk.load(krs, 0);
   sv.load(vrs, 0);
   sk.store(smem);
@@ -714,7 +718,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   if (t < nt) tile(ic<0>{}, t);
 
   if (qvalid) {
-    float* row = dq + base + (size_t)qrow * D;
+    float* row = dq + base + (size_t)qrow * ld;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -741,7 +745,7 @@ probe_kernel(const T* __restrict__ tile_in /*[64][D]*/, const T* __restrict__ b_
   lds_char* smem = (lds_char*)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   TileStager<T, D, 64, 256> st;
-  st.init(tid);
+  st.init(tid, D);
   st.load(make_rsrc(tile_in, 64 * D * sizeof(T)), 0);
   st.store(smem);
   __syncthreads();

@@ -89,6 +89,37 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
     return dq, dk, dv
 
 
+def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2):
+    """Forward on (B, N, H, d) tensors -- the layout minitorch's projection writes before its
+    permute(0,2,1,3).contiguous() (minitorch/modules_transfomer.py:67-89): no head-split copies.
+    Returns (out (B, N, H, d) fp32, l (B, H, N), m (B, H, N) or None)."""
+    if q.dim() != 4:
+        raise ValueError("expected (B, N, H, d)")
+    for t in (q, k, v):
+        if not t.is_cuda or t.shape != q.shape or t.dtype != q.dtype or not t.is_contiguous():
+            raise ValueError("q, k, v must be contiguous GPU tensors of one shape and dtype")
+    B, N, H, d = q.shape
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    l = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    m = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if variant == _lib.FA_VARIANT_FA1 else None
+    _lib.check(_lib.core().fa_mi355x_fwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
+                                                _lib.FA_LAYOUT_BNHD, int(bool(causal)), variant, _DTYPES[q.dtype],
+                                                _stream_ptr()))
+    return out, l, m
+
+
+def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2):
+    """Backward on (B, N, H, d) tensors; returns (dq, dk, dv) in the same layout, fp32."""
+    B, N, H, d = q.shape
+    ws = torch.empty(2 * B * H * N, dtype=torch.float32, device=q.device)
+    dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
+    _lib.check(_lib.core().fa_mi355x_bwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
+                                                _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d,
+                                                _lib.FA_LAYOUT_BNHD, int(bool(causal)), variant, _DTYPES[q.dtype],
+                                                _stream_ptr()))
+    return dq, dk, dv
+
+
 class _FlashAttnFn(torch.autograd.Function):
     """Autograd contract of the reference's Flash_Attn / Flash_Attn2 / Flash_Attn_Causal
     (minitorch/tensor_functions.py:462-497): forward returns o and saves (q, k, v, o, l, m, causal);

@@ -97,6 +97,20 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
                          void* workspace, int batch, int N, int d, int causal, int variant, int dtype, int stages,
                          void* stream);
 
+/* The same two operations on the layout the projection writes: SURVEY.md row f1.  minitorch's MultiHeadAttention
+ * produces q, k, v as (B, N, H, d) views and then pays permute(0,2,1,3).contiguous() for each of them, and the
+ * inverse for the output (minitorch/modules_transfomer.py:67-89,137-139): four full-tensor copies per layer.
+ * FA_LAYOUT_BNHD reads and writes [B][N][H][d] directly (element (b,n,h,:) at ((b*N + n)*H + h)*d);
+ * l, m and the workspace stay [B][H][N]. */
+#define FA_LAYOUT_BHND 0
+#define FA_LAYOUT_BNHD 1
+int fa_mi355x_fwd_layout(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H,
+                         int N, int d, int layout, int causal, int variant, int dtype, void* stream);
+int fa_mi355x_bwd_layout(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                         float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
+                         void* workspace, int B, int H, int N, int d, int layout, int causal, int variant, int dtype,
+                         void* stream);
+
 /* Message of the last FA_ERR_* on this thread ("" if none). */
 const char* fa_mi355x_last_error(void);
 

@@ -335,6 +335,31 @@ def test_online_softmax_rescale_branch_is_exercised(dev):
                 assert maxabs(to_np(got), ref[nm]) < t, (causal, tdt, nm, maxabs(to_np(got), ref[nm]), scale)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_bnhd_layout_matches_permuted_copy(dev, dtype, causal):
+    """(B, N, H, d) in and out, no head-split copies.  Must be bit-identical to running the
+    [B*H][N][d] path on permute(0,2,1,3).contiguous() copies (what minitorch/modules_transfomer.py:67-89 does)."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    torch.manual_seed(3)
+    B, N, H, d = 2, 200, 3, 64
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    q, k, v, do = (((torch.rand((B, N, H, d), device="cuda") - 0.5) * 2).to(tdt) for _ in range(4))
+    perm = lambda t: t.permute(0, 2, 1, 3).contiguous()
+    for variant in (_lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2):
+        o, l, m = dev.flash_attn_fwd_bnhd(q, k, v, causal, variant)
+        dq, dk, dv = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant)
+        o_r, l_r, m_r = dev.flash_attn_fwd(perm(q), perm(k), perm(v), causal, variant)
+        g_r = dev.flash_attn_bwd(perm(q), perm(k), perm(v), o_r, perm(do), l_r, m_r, causal, variant)
+        assert o.shape == (B, N, H, d) and l.shape == (B, H, N)
+        assert torch.equal(perm(o), o_r) and torch.equal(l, l_r)
+        if m is not None:
+            assert torch.equal(m, m_r)
+        for a, b in zip((dq, dk, dv), g_r):
+            assert torch.equal(perm(a), b)
+
+
 def test_autograd_functions_follow_reference_contract(dev):
     """Flash_Attn / Flash_Attn2 / Flash_Attn_Causal: forward returns o, backward yields one grad per tensor input
     (minitorch/tensor_functions.py:462-497)."""
