@@ -106,13 +106,6 @@ template <> struct Atom<bf16_t> {
     }
     return __builtin_bit_cast(frag, u);
   }
-  static FA_DEV frag scale(const frag& x, float c) {   // one rounding to bf16 per element
-    frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (bf16_t)((float)x[j] * c);
-    return f;
-  }
-  static FA_DEV frag ones() { frag f; for (int j = 0; j < 8; ++j) f[j] = (bf16_t)1.0f; return f; }
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
@@ -168,8 +161,6 @@ template <> struct Atom<float> {
     for (int j = 0; j < 8; ++j) f[j] = x[8 * s + j];
     return f;
   }
-  static FA_DEV frag scale(const frag& x, float c) { return x * c; }
-  static FA_DEV frag ones() { frag f; for (int j = 0; j < 8; ++j) f[j] = 1.0f; return f; }
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
