@@ -89,9 +89,21 @@ def main():
     def bwd(stages=device_ops.STAGE_ALL):
         device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages)
 
-    def step():
-        fwd()
-        bwd()
+    # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
+    # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
+    STAGES = (("fwd_kernel", fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
+              ("bwd_dkdv_kernel", lambda: bwd(device_ops.STAGE_DKDV)), ("bwd_dq_kernel", lambda: bwd(device_ops.STAGE_DQ)))
+    breakdown = not args.no_kernel_breakdown
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)] \
+        if breakdown else None
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        for i, (_, fn) in enumerate(STAGES):
+            fn()
+            if ev is not None:
+                ev[i + 1].record()
 
     def barrier():
         if world > 1:
@@ -102,8 +114,8 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(events[i] if breakdown else None)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -117,29 +129,17 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * (flops_fw + flops_bw) / (elapsed / args.steps) / 1e12
 
-    # ---- per-kernel durations with HIP events on the launch stream (torch's current stream) ----------
-    def time_ms(fn, iters=10):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
-
+    # ---- per-kernel average launch duration from the HIP events recorded in the timed region -------------------
     kernels = {}
     roofline = None
-    if not args.no_kernel_breakdown:
-        kernels = {
-            "fwd_kernel": (time_ms(fwd), flops_fw),
-            "bwd_prep_kernel": (time_ms(lambda: bwd(device_ops.STAGE_PREP)), 0.0),
-            "bwd_dkdv_kernel": (time_ms(lambda: bwd(device_ops.STAGE_DKDV)), 8.0 * BH * N * N * d * cf),
-            "bwd_dq_kernel": (time_ms(lambda: bwd(device_ops.STAGE_DQ)), 2.0 * BH * N * N * d * cf),
-        }
+    if breakdown:
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
+        alg = {"fwd_kernel": flops_fw, "bwd_prep_kernel": 0.0, "bwd_dkdv_kernel": 8.0 * BH * N * N * d * cf,
+               "bwd_dq_kernel": 2.0 * BH * N * N * d * cf}
+        for i, (name, _) in enumerate(STAGES):
+            ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / args.steps
+            kernels[name] = (ms, alg[name])
         dom = max(kernels, key=lambda n: kernels[n][0])
         dur_ms, fl = kernels[dom]
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
