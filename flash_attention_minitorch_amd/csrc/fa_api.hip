@@ -82,7 +82,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
   constexpr int RPB = 256 / (D / 8);
   if (stages & FA_BWD_STAGE_PREP) {
     hipLaunchKernelGGL((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
-                       (const T*)dout, l, m, nlc, delta, rows, N, lay, variant);
+                       (const T*)dout, l, m, nlc, delta, rows, N, lay, variant, 1.0f / tau);
     FA_HIP_TRY(hipGetLastError());
   }
   if (stages & FA_BWD_STAGE_DKDV) {
@@ -95,10 +95,14 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 8, 128, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 2)
         rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 9)   // diagnostic build with phase stamps (never timed)
-        rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else
+      else if (g_tuning[0] == 4 || D != 64)   // compiler-interleaved software pipeline (the d = 32 default)
         rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      else if (g_tuning[0] == 93)   // slot-interleaved path with phase stamps (never timed)
+        rc = dkdv_launch<T, D, 32, 8, 128, 93>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      else if (g_tuning[0] == 9)   // phased path with phase stamps (never timed)
+        rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      else   // d = 64 default: slot-interleaved fast path (MFMA slots with pinned VALU / LDS fillers)
+        rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {
       if (g_tuning[0] == 1)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Runs the DIAGNOSTIC dK/dV build (in-kernel s_memtime stamps) at the metric shape and prints the share of each
-loop phase in a wave's life.  Read the SHARES, not the run time (the stamps forbid overlaps the real kernel has)."""
+"""Runs a DIAGNOSTIC dK/dV build (in-kernel s_memtime stamps) at the metric shape and prints the share of each
+loop phase in a wave's life.  Read the SHARES, not the run time (the stamps forbid overlaps the real kernel has).
+usage: phase_cycles.py [9 | 93]     9 = phased kernel, 93 = slot-interleaved kernel"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,17 +13,27 @@ q, k, v, do = mk(), mk(), mk(), mk()
 o, L, _ = device_ops.flash_attn_fwd(q, k, v)
 core = _lib.core()
 core.fa_mi355x_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
-core.fa_mi355x_set_tuning(0, 9)
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+core.fa_mi355x_set_tuning(0, MODE)
 for _ in range(3):
     device_ops.flash_attn_bwd(q, k, v, o, do, L, stages=device_ops.STAGE_PREP | device_ops.STAGE_DKDV)
 torch.cuda.synchronize()
 buf = np.zeros(8 * 8192, dtype=np.uint64)
 _lib.check(core.fa_mi355x_debug_phase_cycles(buf.ctypes.data, buf.size))
 core.fa_mi355x_set_tuning(0, 0)
-ph = buf.reshape(8192, 8)[:, :6].astype(np.float64)
+allc = buf.reshape(8192, 8).astype(np.float64)
+ph = allc[:, :6]
 tot = ph.sum(axis=1)
-names = ["stage_load issue", "row reads + MFMA S,dP issue", "exp/fma/mul/pack (incl. MFMA drain)", "tr reads + MFMA dV,dK issue",
-         "stage_store (incl. vmcnt wait)", "barrier"]
-print("waves:", len(tot), "median cycles per wave:", np.median(tot), "per 32-query sub-slice:", np.median(tot) / 128)
+life, real = allc[:, 6], allc[:, 7]
+ok = real > 0
+print("in-kernel clock GHz (median over waves):", round(float(np.median(life[ok] / real[ok])) * 0.1, 3),
+      " wave lifetime cycles:", np.median(life[ok]), " stamped cycles:", np.median(tot))
+if MODE == 93:
+    names = ["stage_load issue", "prologue period (8 MFMA: S,dP of sub 0)", "periods 1-3 (48 MFMA + VALU)",
+             "last period (8 MFMA + VALU of sub 3)", "stage_store (incl. vmcnt wait)", "barrier"]
+else:
+    names = ["stage_load issue", "row reads + MFMA S,dP issue", "exp/fma/mul/pack (incl. MFMA drain)",
+             "tr reads + MFMA dV,dK issue", "stage_store (incl. vmcnt wait)", "barrier"]
+print("waves:", len(tot), "per 128-query stage:", np.median(tot) / 32, "per 32-query sub-slice:", np.median(tot) / 128)
 for j, nm in enumerate(names):
-    print(f"{nm:40s} {100 * np.median(ph[:, j] / tot):5.1f} %   ({np.median(ph[:, j]) / 128:7.1f} cycles per sub-slice)")
+    print(f"{nm:42s} {100 * np.median(ph[:, j] / tot):5.1f} %   ({np.median(ph[:, j]) / 32:7.1f} cycles per stage)")
