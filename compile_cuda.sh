@@ -15,7 +15,7 @@ mkdir -p "$OUT_DIR"
 CORE="$OUT_DIR/libflash_attn_mi355x.so"
 if [ ! -f "$CORE" ] || [ -n "$(find "$SRC" "$HERE/include" -newer "$CORE" \( -name '*.h' -o -name '*.hip' \) -print -quit)" ]; then
   echo "[compile_cuda.sh] hipcc --offload-arch=$ARCH  fa_api.hip -> $CORE"
-  "$HIPCC" --offload-arch="$ARCH" -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 ${FA_EXTRA_FLAGS:-} \
+  "$HIPCC" --offload-arch="$ARCH" -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize ${FA_EXTRA_FLAGS:-} \
       "$SRC/fa_api.hip" -o "$CORE"
 else
   echo "[compile_cuda.sh] $CORE is up to date"

@@ -48,6 +48,16 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
 template <typename T, int D>
 int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    // FA-2 side output, bf16, d = 64: slot-interleaved three-deep pipeline (tuning key 1 = 2 selects the phased kernel)
+    if (variant == FA_VARIANT_FA2 && g_tuning[1] != 2) {
+      const int nqb = (N + 255) / 256;
+      hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+                         (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
+      FA_HIP_TRY(hipGetLastError());
+      return FA_OK;
+    }
+  }
   return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, lay, causal, variant, tau,
                                                              st);
 }
@@ -67,6 +77,16 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
               float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
   hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+                     (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
+template <typename T, int D, int DIAG = 0>
+int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
+                   float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
+  const int nqb = (N + 255) / 256;
+  hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, DIAG>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                      (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
@@ -122,7 +142,16 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-    } else if constexpr (sizeof(T) == 2) {   // d <= 64: 32-key tiles run 3 waves/SIMD (154 VGPRs), measured 2 % faster
+    } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
+      if (g_tuning[2] == 1)
+        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+      else if (g_tuning[2] == 2)
+        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+      else if (g_tuning[2] == 93)   // phase stamps (never timed)
+        rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+      else
+        rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+    } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
       if (g_tuning[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else

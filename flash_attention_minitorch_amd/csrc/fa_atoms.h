@@ -182,6 +182,27 @@ FA_DEV rsrc_t make_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// LDS-DMA: 64 lanes x 16 B of global memory land lane-linearly at LDS byte address lds_dst (wave-uniform) with no
+// VGPR destination.  Issued as inline asm on purpose: hipcc counts a builtin LDS-DMA as a pending LDS write and then
+// waits vmcnt(0) in front of the next transposed LDS read, which would serialise the copy with the tile loop.  The
+// asm form is invisible to that bookkeeping, so the ISSUER must wait (dma_wait_all) before the barrier that
+// publishes the data.  M0 (the destination base) is saved and restored inside the statement.
+typedef u32x4 raw_rsrc_t;
+FA_DEV raw_rsrc_t make_raw_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  raw_rsrc_t r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+  return r;
+}
+FA_DEV void dma16(raw_rsrc_t rs, uint32_t lds_dst, int voff, int soff) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+}
+FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Register-staged global -> LDS tile copy of ROWS x D elements by NT threads, split into an early issue (load)
 // and a late LDS write (store) so the HBM/L2 latency hides under the MFMA phase in between.
 template <typename T, int D, int ROWS, int NT> struct TileStager {

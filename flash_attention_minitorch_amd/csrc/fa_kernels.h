@@ -256,6 +256,256 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward, slot-interleaved (bf16, d = 64, FA-2 side output): a workgroup = 8 waves = 256 query rows (two waves per
+// SIMD), query on the lane as above.  K / V arrive by LDS-DMA in stages of 128 keys (three-slot rings, V 48 KiB above
+// K) and are consumed as 32-key sub-tiles by a three-deep software pipeline of MFMA slots (see the dK/dV kernel):
+//   period j = 8 slots:   slots 0-3  S^T(j+1) = K Q^T          slots 4-7  O^T += V^T P^T(j-1)
+// with the fma / exp / add / pack of sub-tile j spread over all eight.  At d = 64 the softmax is 36 issue cycles per
+// slot against the 24 an MFMA leaves free: this kernel is VALU-issue bound by construction, the slots only make the
+// MFMAs disappear under it.  Reference handling as in fwd_kernel: the first sub-tile sets the per-row reference to its
+// row maximum; afterwards P is computed against the reference with no maximum, and a lane whose partial row sum
+// reaches 2^6 (rare) makes the wave redo that sub-tile the classic way (scores again from LDS, true maximum,
+// reference moved, O and l rescaled) at the end of its period, before its P.V is issued.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int DIAG = 0>
+__global__ void __launch_bounds__(512)
+fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
+                float* __restrict__ aux_l, int N, int nqb, int BH, Layout lay, int causal, float tau) {
+  static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
+  using A = Atom<T>;
+  typedef typename A::frag frag;
+  constexpr int KC = D / 16, ST = 128;
+  constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB
+  constexpr int VOFF = 3 * TB;
+  __shared__ __attribute__((aligned(16))) char smem_raw[6 * TB];
+  lds_char* smem = (lds_char*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, qb;
+  map_block(blockIdx.x, BH, nqb, bh, qb);
+  if (causal) qb = nqb - 1 - qb;
+  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
+  const bool qvalid = qrow < N;
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const raw_rsrc_t kraw = make_raw_rsrc(k + base, mat_bytes), vraw = make_raw_rsrc(v + base, mat_bytes);
+  const float c = tau * LOG2E;
+
+  frag qf[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
+  f32x16 acc_o[2];
+  acc_o[0] = zero16();
+  acc_o[1] = zero16();
+  float m_ref = 0.f, nmc = 0.f, l_run = 0.f;
+
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+  const int kmax = causal ? min(N, qb * 256 + 256) : N;
+  const int nstage = (kmax + ST - 1) / ST;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
+  const int dma_row7 = (lane >> 2) & 7;
+  const int dma_voff = dma_row7 * ld * (int)sizeof(T) +
+                       16 * (4 * (lane >> 5) + ((lane & 3) ^ ((2 * (w & 1) + (dma_row7 >> 2)) & 3)));
+  auto stage_dma = [&](int row0, int slot_base) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int g = w + 8 * g2;
+      const int soff = (row0 + 8 * g) * ld * (int)sizeof(T);
+      dma16(kraw, smem_addr + slot_base + 1024 * g, dma_voff, soff);
+      dma16(vraw, smem_addr + slot_base + VOFF + 1024 * g, dma_voff, soff);
+    }
+  };
+  stage_dma(0, 0);
+  dma_wait_all();
+  __syncthreads();
+
+  f32x16 sA, sB;
+  u32x4 pA0, pA1, pB0, pB1;   // packed P^T (bf16 pairs): chunks s2 = 0, 1 of the two sub-tiles in flight
+  frag rk[4], tf[4];
+  auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+  auto krow = [&](int b0, int b1, int sub, int kc) -> frag {
+    return *FA_LDS(frag, smem + ((kc & 1) ? b1 : b0) + (D / 32) * 512 * (4 * sub) + 512 * (kc >> 1));
+  };
+  auto vtr = [&](int b0, int b1, int sub, int s2, int dt) -> frag {
+    const int kk = VOFF + (D / 32) * 512 * (4 * sub + 2 * s2) + 512 * dt;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b0 + kk));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b1 + kk + (D / 32) * 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto cvt2 = [&](float a, float b) -> uint32_t {
+    f32x2 pr = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+  };
+  auto mask_scores = [&](f32x16& x, int kcur) {   // raw scores of keys beyond N or (causal) beyond the query: -inf
+    const int klim = causal ? (min(qrow, N - 1) - kcur) : (N - 1 - kcur);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (acc_row(i, h) > klim) x[i] = -INFINITY;
+  };
+  auto tile_max = [&](const f32x16& x) {
+    float mx = x[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, x[i]);
+    return xhalf_max(mx);
+  };
+  // One period.  SUBN / rn*: sub-tile whose S^T is produced; SUBP / tp*: sub-tile whose P.V is issued; SUB2 / r2*: the
+  // sub-tile two ahead (its K rows are requested in slots 6, 7); SUBC / rc* / kcur: the sub-tile in the softmax stream.
+  auto period = [&](auto hn_c, auto hc_c, auto hp_c, auto mask_c, auto subn_c, auto subp_c, auto sub2_c, auto subc_c,
+                    int tp0, int tp1, int r20, int r21, int rc0, int rc1, int kcur, f32x16& ns, f32x16& cs,
+                    u32x4& pp0, u32x4& pp1, u32x4& pc0, u32x4& pc1) {
+    constexpr bool HN = decltype(hn_c)::value != 0, HC = decltype(hc_c)::value != 0, HP = decltype(hp_c)::value != 0;
+    constexpr bool MASK = decltype(mask_c)::value != 0;
+    constexpr int SUBN = decltype(subn_c)::value, SUBP = decltype(subp_c)::value, SUB2 = decltype(sub2_c)::value;
+    constexpr int SUBC = decltype(subc_c)::value;
+    (void)SUBN;
+    float rs = 0.f, cm = c;
+    if constexpr (MASK) {
+      asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the two variants' common fma out of the branch
+      if constexpr (HC) mask_scores(cs, kcur);
+    }
+    auto fe = [&](int i) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nmc));
+      cs[i] = pv;
+      rs += pv;
+    };
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3: S^T of the next sub-tile
+      if constexpr (HN) {
+        if (kq == 0) A::mma_c(ns, rk[0], qf[0], zero16());
+        else A::mma(ns, rk[kq], qf[kq]);
+        SB();   // the MFMA opens its slot; the fillers follow in its shadow
+      }
+      if constexpr (HC) {
+        fe(2 * kq); fe(2 * kq + 1);
+        if (kq >= 1) pc0[kq - 1] = cvt2(cs[2 * kq - 2], cs[2 * kq - 1]);
+      }
+      if constexpr (HP) {
+        if (kq >= 2) tf[kq - 2] = vtr(tp0, tp1, SUBP, 0, kq - 2);
+      }
+      SB();
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 4-7: P.V of the previous sub-tile
+      if constexpr (HP) {
+        A::mma(acc_o[kq & 1], tf[kq], __builtin_bit_cast(frag, (kq < 2) ? pp0 : pp1));
+        SB();
+        if (kq < 2) tf[2 + kq] = vtr(tp0, tp1, SUBP, 1, kq);
+      }
+      if constexpr (HC) {
+        fe(8 + 2 * kq); fe(9 + 2 * kq);
+        if (kq == 0) pc0[3] = cvt2(cs[6], cs[7]);
+        else pc1[kq - 1] = cvt2(cs[6 + 2 * kq], cs[7 + 2 * kq]);
+        if (kq == 3) pc1[3] = cvt2(cs[14], cs[15]);
+      }
+      if constexpr (HN) {
+        if (kq >= 2) {
+          rk[2 * (kq - 2)] = krow(r20, r21, SUB2, 2 * (kq - 2));
+          rk[2 * (kq - 2) + 1] = krow(r20, r21, SUB2, 2 * (kq - 2) + 1);
+        }
+      }
+      SB();
+    }
+    if constexpr (HC) {
+      float alpha = 1.0f;
+      if (__any(!(rs < MAX_DEFER_SUM))) {   // rare: some row outgrew its reference -> redo this sub-tile the classic way
+        frag kk[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) kk[kc] = krow(rc0, rc1, SUBC, kc);
+        A::mma_c(cs, kk[0], qf[0], zero16());
+#pragma unroll
+        for (int kc = 1; kc < 4; ++kc) A::mma(cs, kk[kc], qf[kc]);
+        if constexpr (MASK) mask_scores(cs, kcur);
+        const float delta = fmaxf(tile_max(cs) - m_ref, 0.f);
+        alpha = __builtin_amdgcn_exp2f(-delta * c);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
+        m_ref += delta;
+        nmc = -m_ref * c;
+        rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          cs[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], c, nmc));
+          rs += cs[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pc0[j] = cvt2(cs[2 * j], cs[2 * j + 1]);
+          pc1[j] = cvt2(cs[8 + 2 * j], cs[9 + 2 * j]);
+        }
+      }
+      l_run = l_run * alpha + rs;
+    }
+  };
+  auto T1 = ic<1>{};
+  auto T0 = ic<0>{};
+  auto slot_of = [&](int st) { return (st % 3) * TB; };
+  int cr0 = ra.b[0], cr1 = ra.b[1];
+  int ct0 = ta.b[0], ct1 = ta.b[1];
+  int pt0 = ct0, pt1 = ct1;
+  // prologue: S^T of sub-tile 0, whose row maximum becomes the reference
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) rk[kc] = krow(cr0, cr1, 0, kc);
+  pB0 = pB1 = pA0 = pA1 = u32x4{0u, 0u, 0u, 0u};
+  SB();
+  period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, ic<0>{}, ct0, ct1, cr0, cr1, cr0, cr1, 0, sA, sB, pB0, pB1, pA0, pA1);
+  {
+    const bool m0 = (31 >= N) || (causal && 31 > q0);
+    if (m0) mask_scores(sA, 0);
+    m_ref = tile_max(sA);      // key 0 is never masked, so the maximum is finite
+    nmc = -m_ref * c;
+  }
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    const int nb = slot_of(st + 1);
+    const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;
+    if (more) stage_dma((st + 1) * ST, nb);
+    const int kb = st * ST;
+    // sub-tile 0 of stage 0 was masked in the prologue already (masking twice is harmless)
+    auto need = [&](int sub) { return (kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0); };
+    // period 4st+0: produce sub 1, softmax of sub 0, P.V of sub 3 of the previous stage
+    if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+    else         period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+    // period 4st+1: produce sub 2, softmax of sub 1, P.V of sub 0
+    if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+    else         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+    dma_wait_all();   // this wave's pieces of the next stage have landed
+    __syncthreads();
+    // period 4st+2: produce sub 3, softmax of sub 2, P.V of sub 1; rows two ahead = sub 0 of the next stage
+    if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
+    else         period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
+    // period 4st+3: produce sub 0 of the next stage, softmax of sub 3, P.V of sub 2
+    if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
+    else         period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
+    pt0 = ct0; pt1 = ct1;
+    cr0 = nr0; cr1 = nr1;
+    ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
+  }
+  // drain: P.V of the last sub-tile
+  period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, ic<0>{}, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
+
+  const float l_tot = xhalf_sum(l_run);
+  const float inv = 1.0f / l_tot;
+  if (qvalid) {
+    float* orow = o + base + (size_t)qrow * ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 val = {acc_o[dt][4 * g] * inv, acc_o[dt][4 * g + 1] * inv, acc_o[dt][4 * g + 2] * inv,
+                     acc_o[dt][4 * g + 3] * inv};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = val;
+      }
+    if (h == 0) aux_l[(size_t)bh * N + qrow] = m_ref * tau + __logf(l_tot);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward preprocess: ndelta = -rowsum(dO * O), nlc = -L / tau (raw score units) with L = m + log(l) (FA-1 side
 // outputs) or L = l (FA-2), so that P = exp2(tau*log2e * ((q.k) + nlc)) and dS = P * (dO.V^T + ndelta): both row
 // constants enter the main kernels as MFMA accumulator inputs (S' = Q.K^T + nlc, dP' = dO.V^T + ndelta).  The reference recomputes D_i per (i, j) tile
@@ -424,13 +674,14 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
             if constexpr (HN) {
               if (kq == 0) A::mma_c(ns, rq[0], kf[0][0], cS);
               else A::mma(ns, rq[kq], kf[0][kq]);
+              SB();   // the MFMA opens its slot; the fillers follow in its shadow
               if (kq < 3) rdo[kq + 1] = A::template row_frag<D>(tdo, ra, 32 * SNc, kq + 1);
             }
             if constexpr (HC) { me(cs, 2 * kq); me(cs, 2 * kq + 1); }
             SB();
           }
           // slot 4
-          if constexpr (HN) A::mma_c(ndp, rdo[0], vf[0][0], cD);
+          if constexpr (HN) { A::mma_c(ndp, rdo[0], vf[0][0], cD); SB(); }
           if constexpr (HC) {
             pf0 = A::pack(cs, 0);
             cdp[0] = cs[0] * cdp[0];
@@ -440,7 +691,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           // slots 5-7
 #pragma unroll
           for (int kq = 1; kq < 4; ++kq) {
-            if constexpr (HN) A::mma(ndp, rdo[kq], vf[0][kq]);
+            if constexpr (HN) { A::mma(ndp, rdo[kq], vf[0][kq]); SB(); }
             if constexpr (HC) {
               me(cs, 6 + 2 * kq); me(cs, 7 + 2 * kq);
               tf[kq] = A::template tr_frag<D>(tdo, ta, 32 * SCc + 16 * (kq >> 1), kq & 1);
@@ -450,29 +701,34 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           if constexpr (HC) {
             // slot 8
             A::mma(acc_dv[0][0], tf[0], pf0);
+            SB();
             me(cs, 14); me(cs, 15);
             tf[0] = A::template tr_frag<D>(tq, ta, 32 * SCc, 0);
             SB();
             // slot 9
             A::mma(acc_dv[1][0], tf[1], pf0);
+            SB();
             pf1 = A::pack(cs, 1);
             cdp[1] = cs[1] * cdp[1];
             tf[1] = A::template tr_frag<D>(tq, ta, 32 * SCc, 1);
             SB();
             // slot 10
             A::mma(acc_dv[0][0], tf[2], pf1);
+            SB();
 #pragma unroll
             for (int i = 2; i < 8; ++i) cdp[i] = cs[i] * cdp[i];
             tf[2] = A::template tr_frag<D>(tq, ta, 32 * SCc + 16, 0);
             SB();
             // slot 11
             A::mma(acc_dv[1][0], tf[3], pf1);
+            SB();
             df0 = A::pack(cdp, 0);
             cdp[8] = cs[8] * cdp[8];
             tf[3] = A::template tr_frag<D>(tq, ta, 32 * SCc + 16, 1);
             SB();
             // slot 12
             A::mma(acc_dk[0][0], tf[0], df0);
+            SB();
 #pragma unroll
             for (int i = 9; i < 15; ++i) cdp[i] = cs[i] * cdp[i];
           }
@@ -484,6 +740,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           // slot 13
           if constexpr (HC) {
             A::mma(acc_dk[1][0], tf[1], df0);
+            SB();
             cdp[15] = cs[15] * cdp[15];
             df1 = A::pack(cdp, 1);
           }
@@ -493,11 +750,11 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           }
           SB();
           // slot 14
-          if constexpr (HC) A::mma(acc_dk[0][0], tf[2], df1);
+          if constexpr (HC) { A::mma(acc_dk[0][0], tf[2], df1); SB(); }
           if constexpr (HP) ld_c(cS, 0, SNc + 1);
           SB();
           // slot 15
-          if constexpr (HC) A::mma(acc_dk[1][0], tf[3], df1);
+          if constexpr (HC) { A::mma(acc_dk[1][0], tf[3], df1); SB(); }
           if constexpr (HP) {
             ld_c(cD, 4 * QS, SNc + 1);
             rdo[0] = A::template row_frag<D>(tdo, ra, 32 * (SNc + 1), 0);
@@ -864,6 +1121,254 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     float* row = dq + base + (size_t)qrow * ld;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 val = {acc[dt][4 * g] * tau, acc[dt][4 * g + 1] * tau, acc[dt][4 * g + 2] * tau,
+                     acc[dt][4 * g + 3] * tau};
+        *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * h) = val;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward dQ, slot-interleaved (bf16, d = 64): a workgroup = 8 waves = 256 query rows (two waves per SIMD), the query
+// on the lane as above.  Keys arrive in stages of 128 (K in a three-slot LDS ring, V in the matching slot 48 KiB
+// higher, so V reads share K's address registers) and are consumed as 32-key sub-tiles by a three-deep software
+// pipeline laid out in MFMA slots (see the dK/dV kernel): period j = 12 slots
+//   slots 0-3   S^T(j+1) = K Q^T          slots 4-7   dP^T(j+1) = V dO^T - delta      slots 8-11  dQ^T += K^T dS^T(j-1)
+// with the exp / mul / pack of sub-tile j spread over all twelve (24 issue cycles each) and every LDS fragment
+// requested four slots ahead.  The pipeline never drains at a stage boundary: the barrier that publishes stage s+1
+// sits in the middle of period 4s+2, and a stage's K slot is read (transposed, for dQ) two periods into the next
+// stage, hence the third ring slot.  Whole stages are always processed; sub-tiles beyond the causal diagonal or
+// N are masked (P = 0).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int DIAG = 0>
+__global__ void __launch_bounds__(512)
+bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
+                   const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
+                   int BH, Layout lay, int causal, float tau) {
+  static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
+  using A = Atom<T>;
+  typedef typename A::frag frag;
+  constexpr int KC = D / 16, ST = 128, NT = 512;
+  constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB
+  constexpr int VOFF = 3 * TB;                        // V slot = K slot + 48 KiB
+  __shared__ __attribute__((aligned(16))) char smem_raw[6 * TB];
+  lds_char* smem = (lds_char*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, qb;
+  map_block(blockIdx.x, BH, nqb, bh, qb);
+  if (causal) qb = nqb - 1 - qb;
+  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
+  const bool qvalid = qrow < N;
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
+  const float c = tau * LOG2E;
+
+  frag qf[KC], dof[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int off = (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T);
+    qf[kc] = load_frag_buf<T>(qrs, off);
+    dof[kc] = load_frag_buf<T>(dors, off);
+  }
+  const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
+  const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  f32x16 nd16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nd16[i] = ndq;
+  f32x16 acc[2];
+  acc[0] = zero16();
+  acc[1] = zero16();
+
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+  const int kmax = causal ? min(N, qb * 256 + 256) : N;
+  const int nstage = (kmax + ST - 1) / ST;
+  // Stage loads go global -> LDS directly (buffer_load ... lds, 1 KiB = 8 rows per wave-instruction, no staging
+  // registers): LDS-DMA writes lane-linearly, so the image's chunk swizzle is applied to each lane's SOURCE address.
+  // Wave w moves the 8-row groups w and w + 8 of K and of V (same parity, hence one lane offset).
+  const raw_rsrc_t kraw = make_raw_rsrc(k + base, mat_bytes), vraw = make_raw_rsrc(v + base, mat_bytes);
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
+  const int dma_row7 = (lane >> 2) & 7;
+  const int dma_voff = dma_row7 * ld * (int)sizeof(T) +
+                       16 * (4 * (lane >> 5) + ((lane & 3) ^ ((2 * (w & 1) + (dma_row7 >> 2)) & 3)));
+  auto stage_dma = [&](int row0, int slot_base) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int g = w + 8 * g2;
+      const int soff = (row0 + 8 * g) * ld * (int)sizeof(T);
+      dma16(kraw, smem_addr + slot_base + 1024 * g, dma_voff, soff);
+      dma16(vraw, smem_addr + slot_base + VOFF + 1024 * g, dma_voff, soff);
+    }
+  };
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
+  if constexpr (DIAG) {
+    k_t0 = stamp();
+    k_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  stage_dma(0, 0);
+  dma_wait_all();   // this wave's pieces have landed
+  __syncthreads();
+  if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
+
+  // sub-tile state: A / B alternate between "being produced" and "being consumed"
+  f32x16 sA, dpA, sB, dpB;
+  frag dsA0, dsA1, dsB0, dsB1;   // packed dS^T of the sub-tile before the current one / of the current one
+  frag rk[4], rv[4], tf[4];
+  auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+  // LDS readers on a per-stage address register + immediate
+  auto krow = [&](int b0, int b1, int sub, int kc) -> frag {
+    return *FA_LDS(frag, smem + ((kc & 1) ? b1 : b0) + (D / 32) * 512 * (4 * sub) + 512 * (kc >> 1));
+  };
+  auto ktr = [&](int b0, int b1, int sub, int s2, int dt) -> frag {
+    const int kk = (D / 32) * 512 * (4 * sub + 2 * s2) + 512 * dt;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b0 + kk));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b1 + kk + (D / 32) * 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  // One period.  SUBN: sub-tile (0..3) whose S^T / dP^T are produced [row addresses rn*: its stage]; SUBP: the
+  // sub-tile whose dQ product is issued [transposed addresses tp*: its stage]; SUB2: the sub-tile two ahead, whose K
+  // rows are requested in slots 8-11 [row addresses r2*].  kcur: first key of the sub-tile in the exp / mul stream.
+  auto period = [&](auto hn_c, auto hc_c, auto hp_c, auto mask_c, auto subn_c, auto subp_c, auto sub2_c, int rn0, int rn1,
+                    int tp0, int tp1, int r20, int r21, int kcur, f32x16& ns, f32x16& ndp, f32x16& cs, f32x16& cdp,
+                    frag& dp0, frag& dp1, frag& dc0, frag& dc1) {
+    constexpr bool HN = decltype(hn_c)::value != 0, HC = decltype(hc_c)::value != 0, HP = decltype(hp_c)::value != 0;
+    constexpr bool MASK = decltype(mask_c)::value != 0;
+    constexpr int SUBN = decltype(subn_c)::value, SUBP = decltype(subp_c)::value, SUB2 = decltype(sub2_c)::value;
+    const int qlim = min(qrow, N - 1) - kcur;   // keep key offset o iff o <= qlim (non-causal: only the N bound)
+    const int klim = causal ? qlim : (N - 1 - kcur);
+    float cm = c;
+    if constexpr (MASK) asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the masked and unmasked variants' common fma
+    auto fe = [&](int i) {
+      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nlq));
+      if constexpr (MASK) pv = (acc_row(i, h) > klim) ? 0.f : pv;
+      cs[i] = pv;
+    };
+    auto md = [&](int i) { cdp[i] = cs[i] * cdp[i]; };
+    auto vrow = [&](int kq) -> frag {
+      return *FA_LDS(frag, smem + ((kq & 1) ? rn1 : rn0) + VOFF + (D / 32) * 512 * (4 * SUBN) + 512 * (kq >> 1));
+    };
+    // fragments are requested two slots before the MFMA that consumes them (K rows of the next period: slots 10, 11)
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3
+      if constexpr (HN) {
+        if (kq == 0) A::mma_c(ns, rk[0], qf[0], zero16());
+        else A::mma(ns, rk[kq], qf[kq]);
+        SB();   // the MFMA opens its slot; the fillers follow in its shadow
+        if (kq >= 2) rv[kq - 2] = vrow(kq - 2);
+      }
+      if constexpr (HC) { fe(2 * kq); fe(2 * kq + 1); }
+      SB();
+    }
+    // slot 4
+    if constexpr (HN) { A::mma_c(ndp, rv[0], dof[0], nd16); SB(); rv[2] = vrow(2); }
+    if constexpr (HC) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) md(i);
+    }
+    SB();
+    // slot 5
+    if constexpr (HN) { A::mma(ndp, rv[1], dof[1]); SB(); rv[3] = vrow(3); }
+    if constexpr (HC) { md(6); md(7); dc0 = A::pack(cdp, 0); }
+    SB();
+    // slots 6, 7
+#pragma unroll
+    for (int kq = 2; kq < 4; ++kq) {
+      if constexpr (HN) { A::mma(ndp, rv[kq], dof[kq]); SB(); }
+      if constexpr (HC) { fe(4 + 2 * kq); fe(5 + 2 * kq); }
+      if constexpr (HP) tf[kq - 2] = ktr(tp0, tp1, SUBP, 0, kq & 1);
+      SB();
+    }
+    // slots 8, 9
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      if constexpr (HP) { A::mma(acc[kq], tf[kq], dp0); SB(); tf[2 + kq] = ktr(tp0, tp1, SUBP, 1, kq); }
+      if constexpr (HC) { fe(12 + 2 * kq); fe(13 + 2 * kq); }
+      SB();
+    }
+    // slot 10
+    if constexpr (HP) { A::mma(acc[0], tf[2], dp1); SB(); }
+    if constexpr (HC) {
+#pragma unroll
+      for (int i = 8; i < 14; ++i) md(i);
+    }
+    if constexpr (HN) { rk[0] = krow(r20, r21, SUB2, 0); rk[1] = krow(r20, r21, SUB2, 1); }
+    SB();
+    // slot 11
+    if constexpr (HP) { A::mma(acc[1], tf[3], dp1); SB(); }
+    if constexpr (HC) { md(14); md(15); dc1 = A::pack(cdp, 1); }
+    if constexpr (HN) { rk[2] = krow(r20, r21, SUB2, 2); rk[3] = krow(r20, r21, SUB2, 3); }
+    SB();
+  };
+  auto T1 = ic<1>{};
+  auto T0 = ic<0>{};
+  // per-stage address registers: K slot of stage s is s % 3
+  auto slot_of = [&](int st) { return (st % 3) * TB; };
+  int cr0 = ra.b[0], cr1 = ra.b[1];                 // rows of the current stage (slot 0)
+  int ct0 = ta.b[0], ct1 = ta.b[1];                 // transposed reads of the current stage
+  int pt0 = ct0, pt1 = ct1;                         // ... of the previous stage (stage 0: any finite data, dS = 0)
+  // prologue: rows of sub-tile 0, then S^T(0), dP^T(0)
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) rk[kc] = krow(cr0, cr1, 0, kc);
+  dsB0 = A::zero();
+  dsB1 = A::zero();
+  SB();
+  period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, 0, sA, dpA, sB, dpB, dsB0, dsB1, dsA0, dsA1);
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    const int nb = slot_of(st + 1);
+    const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;   // rows of the next stage
+    if (more) stage_dma((st + 1) * ST, nb);
+    const int kb = st * ST;
+    // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
+    auto need = [&](int sub) { return (kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0); };
+    // period 4st+0: produce sub 1 (this stage), consume sub 0, dQ of sub 3 of the previous stage
+    if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    else         period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    // period 4st+1: produce sub 2, consume sub 1, dQ of sub 0
+    if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    else         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    // the next stage goes to LDS and is published before the second half of period 4st+2 asks for its rows
+    if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
+    dma_wait_all();   // this wave's pieces of the next stage have landed
+    if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
+    __syncthreads();
+    if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+    // period 4st+2: produce sub 3, consume sub 2, dQ of sub 1; rows two ahead = sub 0 of the next stage
+    if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    else         period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    // period 4st+3: produce sub 0 of the next stage, consume sub 3, dQ of sub 2
+    if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    else         period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    pt0 = ct0; pt1 = ct1;
+    cr0 = nr0; cr1 = nr1;
+    ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
+  }
+  // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
+  period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+
+  if constexpr (DIAG) {
+    const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
+    ph[1] += k_t1 - t0;
+    const int slot = blockIdx.x * 8 + w;
+    if (slot < 8192 && lane == 0) {
+      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
+      g_phase_cycles[slot * 8 + 6] = k_t1 - k_t0;
+      g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
+    }
+  }
+  if (qvalid) {
+    float* row = dq + base + (size_t)qrow * ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 val = {acc[dt][4 * g] * tau, acc[dt][4 * g + 1] * tau, acc[dt][4 * g + 2] * tau,

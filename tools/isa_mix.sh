@@ -4,7 +4,7 @@
 set -e
 mkdir -p /tmp/isa && cd /tmp/isa
 if [ -z "$FA_ISA_NOBUILD" ]; then
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 ${FA_EXTRA_FLAGS:-} \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize ${FA_EXTRA_FLAGS:-} \
   -Rpass-analysis=kernel-resource-usage -save-temps /root/repo/flash_attention_minitorch_amd/csrc/fa_api.hip -o /tmp/isa/core.so 2> res.txt
 grep -E "error" -A3 res.txt | head -20 || true
 fi
