@@ -91,8 +91,11 @@ def main():
 
     # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
     # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
-    STAGES = (("fwd_kernel", fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
-              ("bwd_dkdv_kernel", lambda: bwd(device_ops.STAGE_DKDV)), ("bwd_dq_kernel", lambda: bwd(device_ops.STAGE_DQ)))
+    # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
+    slot = args.dtype == "bf16" and d == 64
+    K_FWD, K_DQ = ("fwd_slot_kernel", "bwd_dq_slot_kernel") if slot else ("fwd_kernel", "bwd_dq_kernel")
+    STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
+              ("bwd_dkdv_kernel", lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
     breakdown = not args.no_kernel_breakdown
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)] \
         if breakdown else None
@@ -135,8 +138,8 @@ def main():
     if breakdown:
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
-        alg = {"fwd_kernel": flops_fw, "bwd_prep_kernel": 0.0, "bwd_dkdv_kernel": 8.0 * BH * N * N * d * cf,
-               "bwd_dq_kernel": 2.0 * BH * N * N * d * cf}
+        alg = {K_FWD: flops_fw, "bwd_prep_kernel": 0.0, "bwd_dkdv_kernel": 8.0 * BH * N * N * d * cf,
+               K_DQ: 2.0 * BH * N * N * d * cf}
         for i, (name, _) in enumerate(STAGES):
             ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / args.steps
             kernels[name] = (ms, alg[name])

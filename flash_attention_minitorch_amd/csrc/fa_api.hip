@@ -147,6 +147,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else if (g_tuning[2] == 2)
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+      else if (g_tuning[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
+        rc = dq_slot_launch<T, D, 2>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else if (g_tuning[2] == 93)   // phase stamps (never timed)
         rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else

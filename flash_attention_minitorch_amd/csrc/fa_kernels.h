@@ -1210,14 +1210,14 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     }
   };
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
-  if constexpr (DIAG) {
+  if constexpr (DIAG == 1) {
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
   }
   stage_dma(0, 0);
   dma_wait_all();   // this wave's pieces have landed
   __syncthreads();
-  if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
+  if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
   // sub-tile state: A / B alternate between "being produced" and "being consumed"
   f32x16 sA, dpA, sB, dpB;
@@ -1337,11 +1337,11 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
     else         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
     // the next stage goes to LDS and is published before the second half of period 4st+2 asks for its rows
-    if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
+    if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; }
     dma_wait_all();   // this wave's pieces of the next stage have landed
-    if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
-    __syncthreads();
-    if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+    if constexpr (DIAG == 1) { t0 = stamp(); ph[2] += t0 - t1; }
+    if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
+    if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
     // period 4st+2: produce sub 3, consume sub 2, dQ of sub 1; rows two ahead = sub 0 of the next stage
     if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
     else         period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
@@ -1355,7 +1355,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
   period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
 
-  if constexpr (DIAG) {
+  if constexpr (DIAG == 1) {
     const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
     ph[1] += k_t1 - t0;
     const int slot = blockIdx.x * 8 + w;
