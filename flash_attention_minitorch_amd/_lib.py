@@ -84,6 +84,10 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_fwd_layout.restype = _i
     h.fa_mi355x_bwd_layout.argtypes = [_vp] * 11 + [_i] * 8 + [_vp]
     h.fa_mi355x_bwd_layout.restype = _i
+    h.fa_mi355x_fwd_masked.argtypes = [_vp] * 7 + [_i] * 8 + [_vp]
+    h.fa_mi355x_fwd_masked.restype = _i
+    h.fa_mi355x_bwd_masked.argtypes = [_vp] * 12 + [_i] * 8 + [_vp]
+    h.fa_mi355x_bwd_masked.restype = _i
     h.fa_mi355x_bwd_workspace_bytes.argtypes = [_i, _i, _i]
     h.fa_mi355x_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.fa_mi355x_last_error.argtypes = []

@@ -260,6 +260,11 @@ struct Layout {
   int ld;
   long bstride;
   long hstride;
+  // optional additive key mask [mask_batch][N] (fp32, in units of the SCALED score tau*q.k: 0 keeps a key, -inf drops
+  // it; the reference's fused softmax takes the same [batch, to_len] mask, src/softmax_kernel.cu:27-34,77-90);
+  // batch*head bh reads row bh / mask_heads.  nullptr: no mask.
+  const float* kmask;
+  int mask_heads;
 };
 FA_DEV size_t head_base(const Layout& L, int bh) {
   return (size_t)(bh / L.H) * (size_t)L.bstride + (size_t)(bh % L.H) * (size_t)L.hstride;

@@ -74,7 +74,7 @@ FA_DEV f32x16 zero16() {
 // ---------------------------------------------------------------------------------------------
 constexpr float MAX_DEFER_SUM = 64.0f;   // 2^6: bound on a lane's partial row sum (hence on every P) in the steady state
 
-template <typename T, int D, int BN, int WPE>
+template <typename T, int D, int BN, int WPE, bool HM = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
            float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, Layout lay, int causal,
@@ -84,6 +84,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
   constexpr int TB = A::template tile_bytes<D>(BN);
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
+  __shared__ __attribute__((aligned(16))) float smask[HM ? 2 * BN : 4];   // key mask / tau of the two tiles in flight
   lds_char* smem = (lds_char*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -122,6 +123,22 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   sv.load(vrs, 0);
   sk.store(smem);
   sv.store(smem + 2 * TB);
+  // additive key mask, staged per tile in raw score units (mask / tau) so that it enters S^T as the accumulator input
+  const float* mrow = HM ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const float inv_tau = 1.0f / tau;
+  float mreg = 0.f;
+  auto mask_load = [&](int kb0) {
+    if constexpr (HM) {
+      if (tid < BN) mreg = (kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
+    }
+  };
+  auto mask_store = [&](int par) {
+    if constexpr (HM) {
+      if (tid < BN) smask[par * BN + tid] = mreg;
+    }
+  };
+  mask_load(0);
+  mask_store(0);
   __syncthreads();
 
   auto tile = [&](auto par, auto first_c, int t) {
@@ -132,6 +149,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     if (more) {
       sk.load(krs, kbase + BN);
       sv.load(vrs, kbase + BN);
+      mask_load(kbase + BN);
     }
     lds_char* tk = smem + PAR * TB;
     lds_char* tv = smem + (2 + PAR) * TB;
@@ -143,6 +161,14 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           s[kt] = zero16();
+          if constexpr (HM) {   // register i of lane half h is key 32*kt + acc_row(i, h): four aligned float4 reads
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(&smask[PAR * BN + 32 * kt + 8 * g + 4 * h]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) s[kt][4 * g + j] = mk[j];
+            }
+          }
 #pragma unroll
           for (int kc = 0; kc < KC; ++kc) A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
         }
@@ -181,6 +207,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
       if (FIRST) {                      // the first tile sets the reference to its row maximum
         m_ref = tile_max();
         m_true = m_ref;
+        if (HM && m_ref == -INFINITY) m_ref = 0.f;   // every key of the first tile masked: any finite reference will do
         nmc = -m_ref * c;
         rowsum = exps();
       } else {
@@ -220,6 +247,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     if (more) {
       sk.store(smem + (PAR ^ 1) * TB);
       sv.store(smem + (2 + (PAR ^ 1)) * TB);
+      mask_store(PAR ^ 1);
     }
     __syncthreads();
   };
@@ -232,7 +260,8 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   if (t < nt) tile(ic<1>{}, ic<0>{}, t);
 
   const float l_tot = xhalf_sum(l_run);   // sum of exp2(c*(s - m_ref))
-  const float inv = 1.0f / l_tot;
+  // a row whose every key is masked has l = 0: it returns O = 0 and L = -inf (and zero gradients in the backward)
+  const float inv = (HM && !(l_tot > 0.f)) ? 0.f : 1.0f / l_tot;
   if (qvalid) {
     float* orow = o + base + (size_t)qrow * ld;
 #pragma unroll
@@ -246,7 +275,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
     if (h == 0) {
       const size_t ri = (size_t)bh * N + qrow;
       if (aux_mode == AUX_FA1) {   // l = sum exp(tau*s - m), m = tau * rowmax(s)
-        aux_l[ri] = l_tot * __builtin_amdgcn_exp2f((m_ref - m_true) * c);
+        aux_l[ri] = (HM && !(l_tot > 0.f)) ? 0.f : l_tot * __builtin_amdgcn_exp2f((m_ref - m_true) * c);
         aux_m[ri] = m_true * tau;
       } else {
         aux_l[ri] = m_ref * tau + __logf(l_tot);
@@ -536,7 +565,7 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
   if (row < rows && part == 0) {
     ndelta[row] = -sum;
     const float L = (aux_mode == AUX_FA1) ? (m[row] + __logf(l[row])) : l[row];
-    nlc[row] = -L * inv_tau;
+    nlc[row] = (L == -INFINITY) ? -INFINITY : -L * inv_tau;   // fully masked row: P = exp2(c * (S - inf)) = 0
   }
 }
 
@@ -583,6 +612,14 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       kf[kt][kc] = load_frag_buf<T>(krs, off);
       vf[kt][kc] = load_frag_buf<T>(vrs, off);
     }
+  // optional additive key mask: the key is on the lane, so it is one addend per lane and key tile, in log2 units
+  // (P = exp2(c * S' + mask * log2e)); zero without a mask, where the fma costs what the multiply did
+  float km[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = kw0 + 32 * kt + r;
+    km[kt] = (lay.kmask != nullptr && key < N) ? lay.kmask[(size_t)(bh / lay.mask_heads) * N + key] * LOG2E : 0.f;
+  }
   f32x16 acc_dk[DT][KT], acc_dv[DT][KT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
@@ -663,7 +700,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
             for (int j = 0; j < 4; ++j) x[4 * g + j] = a[j];
           }
         };
-        auto me = [&](f32x16& x, int i) { x[i] = __builtin_amdgcn_exp2f(x[i] * c); };
+        auto me = [&](f32x16& x, int i) { x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], c, km[0])); };
         auto period = [&](auto subn_c, auto subc_c, f32x16& ns, f32x16& ndp, f32x16& cs, f32x16& cdp) {
           constexpr int SN = decltype(subn_c)::value, SC = decltype(subc_c)::value;
           constexpr bool HN = SN >= 0, HC = SC >= 0, HP = HN && SN + 1 < NSUB;
@@ -820,7 +857,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            s[kt][i] = __builtin_amdgcn_exp2f(s[kt][i] * c);
+            s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, km[kt]));
             dp[kt][i] = s[kt][i] * dp[kt][i];
           }
 #pragma unroll
@@ -900,7 +937,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(s[kt][i] * c);
+          for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, km[kt]));
         if (need_mask) {   // diagonal slices only (scalar branch)
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt)
@@ -994,7 +1031,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 // ---------------------------------------------------------------------------------------------
 // Backward dQ: same shape as the forward (4 waves x 32 query rows, K/V tiles of BN keys through LDS).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int BN>
+template <typename T, int D, int BN, bool HM = false>
 __global__ void __launch_bounds__(256)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
@@ -1004,6 +1041,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
   constexpr int TB = A::template tile_bytes<D>(BN);
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
+  __shared__ __attribute__((aligned(16))) float smask[HM ? 2 * BN : 4];   // key mask / tau of the two tiles in flight
   lds_char* smem = (lds_char*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -1051,6 +1089,21 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   sv.load(vrs, 0);
   sk.store(smem);
   sv.store(smem + 2 * TB);
+  const float* mrow = HM ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const float inv_tau = 1.0f / tau;
+  float mreg = 0.f;
+  auto mask_load = [&](int kb0) {
+    if constexpr (HM) {
+      if (tid < BN) mreg = (kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
+    }
+  };
+  auto mask_store = [&](int par) {
+    if constexpr (HM) {
+      if (tid < BN) smask[par * BN + tid] = mreg;
+    }
+  };
+  mask_load(0);
+  mask_store(0);
   __syncthreads();
 
   auto tile = [&](auto par, int t) {
@@ -1060,6 +1113,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     if (more) {
       sk.load(krs, kbase + BN);
       sv.load(vrs, kbase + BN);
+      mask_load(kbase + BN);
     }
     lds_char* tk = smem + PAR * TB;
     lds_char* tv = smem + (2 + PAR) * TB;
@@ -1068,7 +1122,16 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
       f32x16 s[KT], dp[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        A::mma_c(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, 0), qf[0], zero16());
+        f32x16 mk16 = zero16();
+        if constexpr (HM) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(&smask[PAR * BN + 32 * kt + 8 * g + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mk16[4 * g + j] = mk[j];
+          }
+        }
+        A::mma_c(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, 0), qf[0], mk16);
         A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], nd16);
 #pragma unroll
         for (int kc = 1; kc < KC; ++kc) {
@@ -1107,6 +1170,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     if (more) {
       sk.store(smem + (PAR ^ 1) * TB);
       sv.store(smem + (2 + (PAR ^ 1)) * TB);
+      mask_store(PAR ^ 1);
     }
     __syncthreads();
   };

@@ -120,6 +120,44 @@ def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant
     return dq, dk, dv
 
 
+def _check_mask(key_mask, q):
+    if q.dim() != 4:
+        raise ValueError("a key mask needs (B, H, N, d) tensors: it is shared by the heads of a batch element")
+    B, H, N, d = q.shape
+    if (not key_mask.is_cuda or key_mask.dtype != torch.float32 or tuple(key_mask.shape) != (B, N)
+            or not key_mask.is_contiguous()):
+        raise ValueError("key_mask must be a contiguous float32 GPU tensor of shape (B, N)")
+    return B, H, N, d
+
+
+def flash_attn_fwd_masked(q, k, v, key_mask, causal=False, variant=_lib.FA_VARIANT_FA2):
+    """Forward with an additive key mask: P = softmax_k(tau * q.k + key_mask[b, k]), the
+    [batch, to_len] mask of the reference's fused softmax (src/softmax_kernel.cu:27-34; 0 keeps a key, -inf drops it).
+    q, k, v: (B, H, N, d); key_mask: (B, N) float32.  Returns (out, l, m) as flash_attn_fwd."""
+    _check_inputs(q, k, v)
+    B, H, N, d = _check_mask(key_mask, q)
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    l = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    m = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if variant == _lib.FA_VARIANT_FA1 else None
+    _lib.check(_lib.core().fa_mi355x_fwd_masked(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), _ptr(key_mask),
+                                                B, H, N, d, _lib.FA_LAYOUT_BHND, int(bool(causal)), variant,
+                                                _DTYPES[q.dtype], _stream_ptr()))
+    return out, l, m
+
+
+def flash_attn_bwd_masked(q, k, v, out, out_grad, l, m, key_mask, causal=False, variant=_lib.FA_VARIANT_FA2):
+    """Backward of flash_attn_fwd_masked; returns (dq, dk, dv) fp32 (no gradient flows into the mask)."""
+    _check_inputs(q, k, v, out_grad)
+    B, H, N, d = _check_mask(key_mask, q)
+    ws = torch.empty(2 * B * H * N, dtype=torch.float32, device=q.device)
+    dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
+    _lib.check(_lib.core().fa_mi355x_bwd_masked(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
+                                                _ptr(dv), _ptr(l), _ptr(m), _ptr(key_mask), _ptr(ws), B, H, N, d,
+                                                _lib.FA_LAYOUT_BHND, int(bool(causal)), variant, _DTYPES[q.dtype],
+                                                _stream_ptr()))
+    return dq, dk, dv
+
+
 class _FlashAttnFn(torch.autograd.Function):
     """Autograd contract of the reference's Flash_Attn / Flash_Attn2 / Flash_Attn_Causal
     (minitorch/tensor_functions.py:462-497): forward returns o and saves (q, k, v, o, l, m, causal);

@@ -111,6 +111,21 @@ int fa_mi355x_bwd_layout(const void* q, const void* k, const void* v, const floa
                          void* workspace, int B, int H, int N, int d, int layout, int causal, int variant, int dtype,
                          void* stream);
 
+/* The same two operations with an additive KEY mask: SURVEY.md row f4.  The reference's flash path has no mask
+ * argument (its tests multiply by an all-ones matrix, kernel_tests/test_flashattn_fw.py:66,71); its fused softmax
+ * does: attn_mask [batch, to_len], 0 for tokens and -inf for padding, added to the scaled score before the row maximum
+ * (src/softmax_kernel.cu:27-34,77-90; minitorch/modules_transfomer.py:131-136).  key_mask: device float [B][N] in those
+ * units (any finite value or -inf), shared by the H heads of a batch element, combined with `causal`; NULL = no mask.
+ * P = softmax_k(tau * q.k + key_mask[b][k]).  A row whose every admissible key is masked returns out = 0, L = -inf
+ * (FA-1: l = 0, m = -inf) and contributes zero gradients.  Layout and the other arguments as fa_mi355x_*_layout. */
+int fa_mi355x_fwd_masked(const void* q, const void* k, const void* v, float* out, float* l, float* m,
+                         const float* key_mask, int B, int H, int N, int d, int layout, int causal, int variant,
+                         int dtype, void* stream);
+int fa_mi355x_bwd_masked(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                         float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
+                         const float* key_mask, void* workspace, int B, int H, int N, int d, int layout, int causal,
+                         int variant, int dtype, void* stream);
+
 /* Message of the last FA_ERR_* on this thread ("" if none). */
 const char* fa_mi355x_last_error(void);
 

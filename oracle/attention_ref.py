@@ -34,6 +34,8 @@ __all__ = [
     "fa1_backward_tiled",
     "fa2_backward_tiled",
     "vanilla_attention_fw_bw_f32",
+    "masked_attention_fw",
+    "masked_attention_bw",
 ]
 
 
@@ -122,6 +124,53 @@ def dense_attention_bw(q, k, v, do, causal: bool = False, dtype=np.float64, o=No
     dq = tau * np.matmul(ds, k)
     dk = tau * np.matmul(np.swapaxes(ds, -1, -2), q)
     return dq, dk, dv
+
+
+def _masked_scores(q, k, key_mask, causal, dtype):
+    """tau * Q K^T + key_mask[..., None, :] with the causal rule applied first, exactly the order of the reference's
+    fused softmax (src/softmax_kernel.cu:77-90: `mask_future` entries become -inf, every other entry gets
+    `+ attn_mask[to]`); attn_mask is [batch, to_len], 0 for tokens and -inf for padding (:27-34), broadcast over heads
+    and queries.  Parity unpinned for the mask itself: the reference implements it only in CUDA (no CPU model, no
+    fixture); tests anchor it on two identities the pinned unmasked oracle provides -- a zero mask changes nothing, and
+    a -inf mask equals attention over the kept keys alone."""
+    s = _scores(q, k, causal, dtype)
+    km = np.asarray(key_mask, dtype=dtype)
+    return s + km[..., None, :]
+
+
+def masked_attention_fw(q, k, v, key_mask, causal: bool = False, dtype=np.float64):
+    """softmax(tau Q K^T + key_mask) V for (..., N, d) arrays and a (..., N) additive key mask broadcast over the
+    leading dims it lacks (give it shape (B, 1, N) for (B, H, N, d) inputs).  Returns (O, L).  A row whose every key
+    is dropped returns O = 0 and L = -inf (the HIP path's documented convention, include/flash_attn_mi355x.h)."""
+    dtype = np.dtype(dtype).type
+    s = _masked_scores(q, k, key_mask, causal, dtype)
+    m = s.max(axis=-1, keepdims=True)
+    dead = ~np.isfinite(m)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = np.exp(s - np.where(dead, 0.0, m))
+        l = p.sum(axis=-1, keepdims=True)
+        o = np.where(dead, 0.0, np.matmul(p, np.asarray(v, dtype=dtype)) / np.where(dead, 1.0, l))
+        L = np.where(dead[..., 0], -np.inf, m[..., 0] + np.log(np.where(dead, 1.0, l))[..., 0])
+    return o, L
+
+
+def masked_attention_bw(q, k, v, do, key_mask, causal: bool = False, dtype=np.float64):
+    """Analytic backward of masked_attention_fw (the algebra of dense_attention_bw; dropped keys have P = 0, fully
+    dropped rows contribute nothing).  Returns (dQ, dK, dV)."""
+    dtype = np.dtype(dtype).type
+    q, k, v, do = (np.asarray(x, dtype=dtype) for x in (q, k, v, do))
+    tau = dtype(_tau(q.shape[-1]))
+    s = _masked_scores(q, k, key_mask, causal, dtype)
+    m = s.max(axis=-1, keepdims=True)
+    dead = ~np.isfinite(m)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = np.exp(s - np.where(dead, 0.0, m))
+        p = np.where(dead, 0.0, p / np.where(dead, 1.0, p.sum(axis=-1, keepdims=True)))
+    o = np.matmul(p, v)
+    dv = np.matmul(np.swapaxes(p, -1, -2), do)
+    dp = np.matmul(do, np.swapaxes(v, -1, -2))
+    ds = p * (dp - (do * o).sum(axis=-1, keepdims=True))
+    return tau * np.matmul(ds, k), tau * np.matmul(np.swapaxes(ds, -1, -2), q), dv
 
 
 def vanilla_attention_fw_bw_f32(q, k, v, do, causal: bool = False):

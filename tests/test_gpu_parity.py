@@ -261,6 +261,54 @@ def test_slot_kernels_block_and_ring_boundaries(dev, N, causal):
         assert maxabs(a, b) < 0.5 * tol, (nm, maxabs(a, b))
 
 
+@pytest.mark.parametrize("dtype,d", [("bf16", 64), ("bf16", 128), ("f32", 32), ("f32", 64)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_key_mask_forward_backward(dev, dtype, d, causal):
+    """additive [B, N] key mask (src/softmax_kernel.cu:27-34,77-90 semantics) inside the fused
+    kernels, FA-1 and FA-2 side outputs, against the oracle's masked_attention_* (itself tied to the pinned dense
+    oracle by identities, tests/test_oracle_golden.py).  Padding (-inf tail), random dropped keys, a finite bias and,
+    under the causal rule, rows whose every admissible key is dropped (O = 0, L = -inf, zero gradients)."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    rng = np.random.default_rng(40 + d)
+    B, H, N = 2, 3, 200
+    arrs = [rand_u(rng, (B, H, N, d)) for _ in range(4)]
+    if dtype == "bf16":
+        arrs = [oracle.bf16_round(a) for a in arrs]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", tdt) for a in arrs)
+    mask = np.zeros((B, N), dtype=np.float32)
+    mask[0, 150:] = -np.inf                                    # padded tail
+    mask[1, rng.uniform(size=N) < 0.3] = -np.inf               # scattered drops
+    mask[1, 5:9] = np.float32(-1.5)                            # finite bias
+    mask[1, 0] = -np.inf                                       # causal: query 0 of batch 1 has no key left
+    tmask = torch.from_numpy(mask).cuda()
+    tol = (TOLBF_CAUSAL if causal else TOLBF) if dtype == "bf16" else TOL32
+    ro, rL = oracle.masked_attention_fw(*arrs[:3], mask[:, None, :], causal)
+    rg = oracle.masked_attention_bw(*arrs, mask[:, None, :], causal)
+    for variant in (_lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2):
+        o, l, m = dev.flash_attn_fwd_masked(tq, tk, tv, tmask, causal, variant)
+        dq, dk, dv = dev.flash_attn_bwd_masked(tq, tk, tv, o, tdo, l, m, tmask, causal, variant)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            L = to_np(m) + np.log(to_np(l)) if variant == _lib.FA_VARIANT_FA1 else to_np(l)
+        dead = np.isneginf(rL)
+        assert dead.any() == causal                              # only the causal case has fully dropped rows
+        assert np.array_equal(np.isneginf(L), dead)
+        assert maxabs(np.where(dead, 0, L), np.where(dead, 0, rL)) < tol
+        assert np.all(np.isfinite(to_np(o))) and maxabs(to_np(o), ro) < tol
+        for nm, got, ref in (("dq", dq, rg[0]), ("dk", dk, rg[1]), ("dv", dv, rg[2])):
+            assert np.all(np.isfinite(to_np(got))), nm
+            assert maxabs(to_np(got), ref) < tol, (nm, maxabs(to_np(got), ref))
+        # dropped keys receive exactly zero gradient
+        drop = np.isneginf(mask)
+        for b in range(B):
+            assert np.all(to_np(dk)[b][:, drop[b]] == 0) and np.all(to_np(dv)[b][:, drop[b]] == 0)
+    # a NULL / all-zero mask is the unmasked operator, bit for bit (same kernels when NULL; same arithmetic when zero)
+    o0, l0, _ = dev.flash_attn_fwd(tq, tk, tv, causal)
+    oz, lz, _ = dev.flash_attn_fwd_masked(tq, tk, tv, torch.zeros((B, N), device="cuda"), causal)
+    assert maxabs(to_np(oz), to_np(o0)) < tol * 0.5 and maxabs(to_np(lz), to_np(l0)) < tol * 0.5
+
+
 def test_long_sequence(dev):
     """N = 8192 against the oracle on one head, and N = 32768 through size-independent properties (no N^2 memory on
     either side: the reference's only sequence-length limit is time)."""

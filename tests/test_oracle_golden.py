@@ -154,3 +154,45 @@ def test_bf16_round_ties_to_even():
     assert np.array_equal(r, t)
     big = np.random.default_rng(0).standard_normal(10000).astype(np.float32)
     assert np.array_equal(oracle.bf16_round(big), torch.from_numpy(big).to(torch.bfloat16).float().numpy())
+
+
+# ---------------------------------------------------------------- additive key mask
+def test_masked_oracle_reduces_to_pinned_unmasked_oracle():
+    """The mask has no reference fixture (CUDA only, src/softmax_kernel.cu:27-34,77-90): it is tied to the pinned dense
+    functions by identities -- a zero mask changes nothing; a -inf mask equals attention over the kept keys alone; a
+    finite mask equals adding it to the scores (checked through the log-sum-exp shift of one key)."""
+    rng = np.random.default_rng(11)
+    B, H, N, d = 2, 3, 37, 16
+    q, k, v, do = (rng.uniform(-1, 1, (B, H, N, d)) for _ in range(4))
+    for causal in (False, True):
+        o0, L0, _, _ = oracle.dense_attention_fw(q, k, v, causal)
+        g0 = oracle.dense_attention_bw(q, k, v, do, causal)
+        zero = np.zeros((B, 1, N))
+        o1, L1 = oracle.masked_attention_fw(q, k, v, zero, causal)
+        g1 = oracle.masked_attention_bw(q, k, v, do, zero, causal)
+        assert np.allclose(o1, o0, atol=1e-13) and np.allclose(L1, L0, atol=1e-13)
+        for a, b in zip(g1, g0):
+            assert np.allclose(a, b, atol=1e-13)
+    # -inf on a key subset == dense attention on the compacted K / V (non-causal: positions do not matter)
+    keep = rng.uniform(size=(B, N)) < 0.6
+    keep[:, 0] = True
+    mask = np.where(keep, 0.0, -np.inf)[:, None, :]
+    o, L = oracle.masked_attention_fw(q, k, v, mask, False)
+    dq, dk, dv = oracle.masked_attention_bw(q, k, v, do, mask, False)
+    for b in range(B):
+        idx = np.nonzero(keep[b])[0]
+        oc, Lc, _, _ = oracle.dense_attention_fw(q[b], k[b][:, idx], v[b][:, idx], False)
+        assert np.allclose(o[b], oc, atol=1e-13) and np.allclose(L[b], Lc, atol=1e-13)
+        # gradients w.r.t. the kept keys match the compacted problem's, dropped keys get exactly zero
+        s = np.matmul(q[b], np.swapaxes(k[b][:, idx], -1, -2)) / np.sqrt(d)
+        p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+        dvc = np.matmul(np.swapaxes(p, -1, -2), do[b])
+        assert np.allclose(dv[b][:, idx], dvc, atol=1e-13)
+        drop = np.nonzero(~keep[b])[0]
+        assert np.all(dv[b][:, drop] == 0) and np.all(dk[b][:, drop] == 0)
+    # fully dropped rows (causal, key 0 masked: query 0 sees nothing): O = 0, L = -inf, finite gradients
+    mask2 = np.zeros((B, 1, N)); mask2[:, :, 0] = -np.inf
+    o2, L2 = oracle.masked_attention_fw(q, k, v, mask2, True)
+    g2 = oracle.masked_attention_bw(q, k, v, do, mask2, True)
+    assert np.all(o2[:, :, 0] == 0) and np.all(np.isneginf(L2[:, :, 0])) and np.all(np.isfinite(o2))
+    assert all(np.all(np.isfinite(g)) for g in g2)
