@@ -88,6 +88,11 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_fwd_masked.restype = _i
     h.fa_mi355x_bwd_masked.argtypes = [_vp] * 12 + [_i] * 8 + [_vp]
     h.fa_mi355x_bwd_masked.restype = _i
+    _f, _u = ctypes.c_float, ctypes.c_uint
+    h.fa_mi355x_fwd_dropout.argtypes = [_vp] * 7 + [_f, _f, _u] + [_i] * 8 + [_vp]
+    h.fa_mi355x_fwd_dropout.restype = _i
+    h.fa_mi355x_bwd_dropout.argtypes = [_vp] * 11 + [_f, _f, _u] + [_vp] + [_i] * 8 + [_vp]
+    h.fa_mi355x_bwd_dropout.restype = _i
     h.fa_mi355x_bwd_workspace_bytes.argtypes = [_i, _i, _i]
     h.fa_mi355x_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.fa_mi355x_last_error.argtypes = []

@@ -39,8 +39,11 @@ template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                    fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
-  if (lay.kmask)   // additive key mask: staged per tile, enters S^T as the accumulator input
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, true>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q,
+  if (lay.drop_thr)   // dropout on P (and the key mask, staged as zeros when absent)
+    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 2>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q,
+                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
+  else if (lay.kmask)   // additive key mask: staged per tile, enters S^T as the accumulator input
+    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 1>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
   else
     hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
@@ -54,7 +57,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
                fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
   if constexpr (sizeof(T) == 2 && D == 64) {
     // FA-2 side output, bf16, d = 64: slot-interleaved three-deep pipeline (tuning key 1 = 2 selects the phased kernel)
-    if (variant == FA_VARIANT_FA2 && g_tuning[1] != 2 && !lay.kmask) {
+    if (variant == FA_VARIANT_FA2 && g_tuning[1] != 2 && !lay.kmask && !lay.drop_thr) {
       const int nqb = (N + 255) / 256;
       hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                          (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
@@ -70,6 +73,13 @@ template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                 float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
+  if (lay.drop_thr) {   // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key)
+    hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
+                       (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
+                       causal, tau);
+    FA_HIP_TRY(hipGetLastError());
+    return FA_OK;
+  }
   hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
                      (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau);
   FA_HIP_TRY(hipGetLastError());
@@ -80,8 +90,11 @@ template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
               float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
-  if (lay.kmask)
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, true>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+  if (lay.drop_thr)
+    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 2>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+  else if (lay.kmask)
+    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 1>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   else
     hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
@@ -153,7 +166,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
       if (g_tuning[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (g_tuning[2] == 2 || lay.kmask)   // the key mask lives in the phased kernel
+      else if (g_tuning[2] == 2 || lay.kmask || lay.drop_thr)   // key mask and dropout live in the phased kernel
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else if (g_tuning[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
         rc = dq_slot_launch<T, D, 2>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
@@ -189,8 +202,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 
 // tau uses the caller's d even when the rows are zero-padded to dp columns (zero columns of Q/K add
 // nothing to the scores; zero columns of V produce zero output columns that are dropped).
-fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1}; }
-fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1}; }
+fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1, 0u, 1.0f, 0u}; }
+fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u}; }
 
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
                  int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st) {
@@ -362,6 +375,55 @@ int fa_mi355x_bwd_masked(const void* q, const void* k, const void* v, const floa
   fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
   lay.kmask = key_mask;
   lay.mask_heads = H;
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
+                      causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream);
+}
+
+namespace {
+int set_dropout(fa::Layout& lay, float rate, float scale, unsigned seed) {
+  if (!(rate >= 0.0f && rate < 1.0f)) return set_err(FA_ERR_BAD_ARG, "dropout rate must be in [0, 1)");
+  lay.drop_thr = (uint32_t)((double)rate * 16777216.0);   // floor(rate * 2^24); 0 disables dropout
+  lay.drop_scale = scale;
+  lay.drop_seed = seed;
+  return FA_OK;
+}
+}  // namespace
+
+int fa_mi355x_fwd_dropout(const void* q, const void* k, const void* v, float* out, float* l, float* m,
+                          const float* key_mask, float rate, float scale, unsigned seed, int B, int H, int N, int d,
+                          int layout, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  lay.kmask = key_mask;
+  lay.mask_heads = H;
+  if (int rc = set_dropout(lay, rate, scale, seed)) return rc;
+  return fwd_dispatch(q, k, v, out, l, m, B * H, N, d, d, lay, causal ? 1 : 0, variant, dtype, (hipStream_t)stream);
+}
+
+int fa_mi355x_bwd_dropout(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                          float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
+                          const float* key_mask, float rate, float scale, unsigned seed, void* workspace, int B, int H,
+                          int N, int d, int layout, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  lay.kmask = key_mask;
+  lay.mask_heads = H;
+  if (int rc = set_dropout(lay, rate, scale, seed)) return rc;
   return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
                       causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream);
 }

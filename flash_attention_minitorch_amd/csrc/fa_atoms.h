@@ -265,7 +265,28 @@ struct Layout {
   // batch*head bh reads row bh / mask_heads.  nullptr: no mask.
   const float* kmask;
   int mask_heads;
+  // optional dropout on the attention probabilities (see drop_keep): drop_thr = 0 disables it
+  uint32_t drop_thr;     // a position is kept iff its 24-bit uniform r24 >= drop_thr  (drop_thr = floor(rate * 2^24))
+  float drop_scale;      // kept probabilities are multiplied by this (1 = minitorch's nn.dropout, 1/(1-rate) = inverted)
+  uint32_t drop_seed;
 };
+
+// Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two
+// multiply / xor-shift rounds) of a seed-offset linear index -- stateless, so the forward, the dK/dV kernel and the dQ
+// kernel regenerate the same mask from their own (register, lane) -> (q, k) maps, and oracle/attention_ref.py restates
+// it in NumPy bit for bit.  minitorch's dropout keeps a position iff rate < r, r uniform in [0,1) (minitorch/nn.py:168-186).
+FA_DEV uint32_t drop_base(const Layout& L, int bh, int q) {
+  return L.drop_seed + (uint32_t)bh * 0xC2B2AE3Du + (uint32_t)q * 0x9E3779B1u;
+}
+FA_DEV bool drop_keep(uint32_t base_bh_q, int k, uint32_t thr) {
+  uint32_t a = base_bh_q + (uint32_t)k * 0x85EBCA77u;
+  a ^= a >> 16;
+  a *= 0x7FEB352Du;
+  a ^= a >> 15;
+  a *= 0x846CA68Bu;
+  a ^= a >> 16;
+  return (a >> 8) >= thr;
+}
 FA_DEV size_t head_base(const Layout& L, int bh) {
   return (size_t)(bh / L.H) * (size_t)L.bstride + (size_t)(bh % L.H) * (size_t)L.hstride;
 }

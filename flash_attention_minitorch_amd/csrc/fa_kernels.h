@@ -74,13 +74,14 @@ FA_DEV f32x16 zero16() {
 // ---------------------------------------------------------------------------------------------
 constexpr float MAX_DEFER_SUM = 64.0f;   // 2^6: bound on a lane's partial row sum (hence on every P) in the steady state
 
-template <typename T, int D, int BN, int WPE, bool HM = false>
+template <typename T, int D, int BN, int WPE, int FEAT = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
            float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, Layout lay, int causal,
            int aux_mode, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
+  constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
   constexpr int TB = A::template tile_bytes<D>(BN);
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
@@ -124,12 +125,13 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   sk.store(smem);
   sv.store(smem + 2 * TB);
   // additive key mask, staged per tile in raw score units (mask / tau) so that it enters S^T as the accumulator input
-  const float* mrow = HM ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const float* mrow = (HM && lay.kmask) ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const uint32_t dbase = HD ? drop_base(lay, bh, qrow) : 0u;
   const float inv_tau = 1.0f / tau;
   float mreg = 0.f;
   auto mask_load = [&](int kb0) {
     if constexpr (HM) {
-      if (tid < BN) mreg = (kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
+      if (tid < BN) mreg = (mrow != nullptr && kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
     }
   };
   auto mask_store = [&](int par) {
@@ -230,6 +232,13 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         }
       }
       l_run = l_run * alpha + rowsum;
+      if constexpr (HD) {   // dropout acts on the normalised probabilities: after the row sum, before P.V
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            s[kt][i] = drop_keep(dbase, kbase + 32 * kt + acc_row(i, h), lay.drop_thr) ? s[kt][i] * lay.drop_scale : 0.f;
+      }
       frag pf[KT][2];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
@@ -574,7 +583,7 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 // the dK^T, dV^T accumulators of its KPW keys in registers while the workgroup sweeps 32-row query slices
 // (Q, dO tiles + their nlc, delta staged in LDS, double buffered).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false>
 __global__ void __launch_bounds__(NW * 64)
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
@@ -685,7 +694,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     //   slots 0-7   S', dP' of sub-slice i+1 (row constants enter as accumulator inputs)   | exp of sub-slice i
     //   slots 8-15  dV^T += dO^T P, dK^T += Q^T dS of sub-slice i                           | mul / pack of sub-slice i
     // LDS fragments are requested four slots before the MFMA that consumes them.
-    constexpr bool SLOT = (MODE == 3 || MODE == 93) && NSUB == 4 && D == 64 && KT == 1 && sizeof(T) == 2;
+    constexpr bool SLOT = !HD && (MODE == 3 || MODE == 93) && NSUB == 4 && D == 64 && KT == 1 && sizeof(T) == 2;
     if constexpr (SLOT) {
       const bool fast3 = (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
       if (fast3) {
@@ -818,7 +827,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     }
     // ---- software-pipelined fast path (stage fully unmasked): S, dP of sub-slice i+1 are issued before the
     // exp / mul / pack work of sub-slice i, so one wave has independent MFMA and VALU streams to interleave.
-    constexpr bool PIPE = MODE == 0 && NSUB == 4 && D <= 64;   // (needs ~250 VGPRs at d = 64; not for d = 128)
+    constexpr bool PIPE = !HD && MODE == 0 && NSUB == 4 && D <= 64;   // (needs ~250 VGPRs at d = 64; not for d = 128)
     const bool fast = PIPE && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
     const bool fast_slot = SLOT && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);
     if (fast_slot) {
@@ -925,7 +934,8 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           for (int kt = 0; kt < KT; ++kt) {
             if (kc == 0) {   // row constants ride in as accumulator inputs: S' = S - L/tau, dP' = dP - delta
               A::mma_c(s[kt], aq, kf[kt][kc], nl16);
-              A::mma_c(dp[kt], ado, vf[kt][kc], nd16);
+              if constexpr (HD) A::mma_c(dp[kt], ado, vf[kt][kc], zero16());   // dropout scales dP before -delta is added
+              else A::mma_c(dp[kt], ado, vf[kt][kc], nd16);
             } else {
               A::mma(s[kt], aq, kf[kt][kc]);
               A::mma(dp[kt], ado, vf[kt][kc]);
@@ -948,7 +958,15 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) dp[kt][i] = s[kt][i] * dp[kt][i];
+          for (int i = 0; i < 16; ++i) {
+            if constexpr (HD) {   // dS = P * (scale * M * dP - delta); the dV product takes scale * M * P
+              const bool keep = drop_keep(drop_base(lay, bh, qi0 + acc_row(i, h)), kw0 + 32 * kt + r, lay.drop_thr);
+              dp[kt][i] = s[kt][i] * ((keep ? dp[kt][i] * lay.drop_scale : 0.f) + nd16[i]);
+              s[kt][i] = keep ? s[kt][i] * lay.drop_scale : 0.f;
+            } else {
+              dp[kt][i] = s[kt][i] * dp[kt][i];
+            }
+          }
         frag pf[KT][2], dsf[KT][2];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -1031,13 +1049,14 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 // ---------------------------------------------------------------------------------------------
 // Backward dQ: same shape as the forward (4 waves x 32 query rows, K/V tiles of BN keys through LDS).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int BN, bool HM = false>
+template <typename T, int D, int BN, int FEAT = 0>
 __global__ void __launch_bounds__(256)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
               int BH, Layout lay, int causal, float tau) {
   using A = Atom<T>;
   typedef typename A::frag frag;
+  constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
   constexpr int TB = A::template tile_bytes<D>(BN);
   __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
@@ -1089,12 +1108,13 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   sv.load(vrs, 0);
   sk.store(smem);
   sv.store(smem + 2 * TB);
-  const float* mrow = HM ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const float* mrow = (HM && lay.kmask) ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const uint32_t dbase = HD ? drop_base(lay, bh, qrow) : 0u;
   const float inv_tau = 1.0f / tau;
   float mreg = 0.f;
   auto mask_load = [&](int kb0) {
     if constexpr (HM) {
-      if (tid < BN) mreg = (kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
+      if (tid < BN) mreg = (mrow != nullptr && kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
     }
   };
   auto mask_store = [&](int par) {
@@ -1132,7 +1152,8 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
           }
         }
         A::mma_c(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, 0), qf[0], mk16);
-        A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], nd16);
+        if constexpr (HD) A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], zero16());
+        else A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], nd16);
 #pragma unroll
         for (int kc = 1; kc < KC; ++kc) {
           A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
@@ -1155,7 +1176,14 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dp[kt][i] = s[kt][i] * dp[kt][i];
+        for (int i = 0; i < 16; ++i) {
+          if constexpr (HD) {
+            const bool keep = drop_keep(dbase, kbase + 32 * kt + acc_row(i, h), lay.drop_thr);
+            dp[kt][i] = s[kt][i] * ((keep ? dp[kt][i] * lay.drop_scale : 0.f) + ndq);
+          } else {
+            dp[kt][i] = s[kt][i] * dp[kt][i];
+          }
+        }
         dsf[kt][0] = A::pack(dp[kt], 0);
         dsf[kt][1] = A::pack(dp[kt], 1);
       }

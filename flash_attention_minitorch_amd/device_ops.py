@@ -158,6 +158,38 @@ def flash_attn_bwd_masked(q, k, v, out, out_grad, l, m, key_mask, causal=False, 
     return dq, dk, dv
 
 
+def flash_attn_fwd_dropout(q, k, v, rate, seed, scale=1.0, key_mask=None, causal=False, variant=_lib.FA_VARIANT_FA2):
+    """Forward with dropout on the attention probabilities (and an optional key mask): out = scale * (M o P) v with the
+    stateless mask of include/flash_attn_mi355x.h (kept iff rate < r, minitorch/nn.py:168-186; scale = 1 is minitorch's
+    convention).  q, k, v: (B, H, N, d).  Returns (out, l, m); l / m are the statistics before dropout."""
+    _check_inputs(q, k, v)
+    if q.dim() != 4:
+        raise ValueError("expected (B, H, N, d)")
+    B, H, N, d = _check_mask(key_mask, q) if key_mask is not None else q.shape
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    l = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    m = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if variant == _lib.FA_VARIANT_FA1 else None
+    _lib.check(_lib.core().fa_mi355x_fwd_dropout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), _ptr(key_mask),
+                                                 float(rate), float(scale), int(seed) & 0xFFFFFFFF, B, H, N, d,
+                                                 _lib.FA_LAYOUT_BHND, int(bool(causal)), variant, _DTYPES[q.dtype],
+                                                 _stream_ptr()))
+    return out, l, m
+
+
+def flash_attn_bwd_dropout(q, k, v, out, out_grad, l, m, rate, seed, scale=1.0, key_mask=None, causal=False,
+                           variant=_lib.FA_VARIANT_FA2):
+    """Backward of flash_attn_fwd_dropout (same rate, seed, scale, mask); returns (dq, dk, dv) fp32."""
+    _check_inputs(q, k, v, out_grad)
+    B, H, N, d = _check_mask(key_mask, q) if key_mask is not None else q.shape
+    ws = torch.empty(2 * B * H * N, dtype=torch.float32, device=q.device)
+    dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
+    _lib.check(_lib.core().fa_mi355x_bwd_dropout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
+                                                 _ptr(dv), _ptr(l), _ptr(m), _ptr(key_mask), float(rate), float(scale),
+                                                 int(seed) & 0xFFFFFFFF, _ptr(ws), B, H, N, d, _lib.FA_LAYOUT_BHND,
+                                                 int(bool(causal)), variant, _DTYPES[q.dtype], _stream_ptr()))
+    return dq, dk, dv
+
+
 class _FlashAttnFn(torch.autograd.Function):
     """Autograd contract of the reference's Flash_Attn / Flash_Attn2 / Flash_Attn_Causal
     (minitorch/tensor_functions.py:462-497): forward returns o and saves (q, k, v, o, l, m, causal);

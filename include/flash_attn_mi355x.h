@@ -126,6 +126,22 @@ int fa_mi355x_bwd_masked(const void* q, const void* k, const void* v, const floa
                          const float* key_mask, void* workspace, int B, int H, int N, int d, int layout, int causal,
                          int variant, int dtype, void* stream);
 
+/* ... and with dropout on the attention probabilities (the other half of SURVEY.md row f4):
+ *   out = scale * (M o softmax(tau*q.k + key_mask)) v,   M[b,h,q,k] = 1 iff r24(seed, b*H+h, q, k) >= floor(rate * 2^24)
+ * minitorch's dropout keeps a position iff rate < r and does NOT rescale (minitorch/nn.py:168-186): scale = 1 is that
+ * convention, scale = 1/(1-rate) the inverted one; the reference's own vanilla-attention test multiplies the
+ * probabilities by such a 0/1 matrix (kernel_tests/test_flashattn_fw.py:66,71).  r24 is the top 24 bits of a stateless
+ * 32-bit hash of (seed, batch*head, query, key) (csrc/fa_atoms.h drop_keep; oracle/attention_ref.py restates it), so the
+ * backward regenerates the same mask: call it with the rate, scale and seed of the forward.  l (and m) are the softmax
+ * statistics BEFORE dropout.  rate = 0 is fa_mi355x_*_masked.  key_mask may be NULL. */
+int fa_mi355x_fwd_dropout(const void* q, const void* k, const void* v, float* out, float* l, float* m,
+                          const float* key_mask, float rate, float scale, unsigned seed, int B, int H, int N, int d,
+                          int layout, int causal, int variant, int dtype, void* stream);
+int fa_mi355x_bwd_dropout(const void* q, const void* k, const void* v, const float* out, const void* out_grad,
+                          float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
+                          const float* key_mask, float rate, float scale, unsigned seed, void* workspace, int B, int H,
+                          int N, int d, int layout, int causal, int variant, int dtype, void* stream);
+
 /* Message of the last FA_ERR_* on this thread ("" if none). */
 const char* fa_mi355x_last_error(void);
 

@@ -36,6 +36,9 @@ __all__ = [
     "vanilla_attention_fw_bw_f32",
     "masked_attention_fw",
     "masked_attention_bw",
+    "dropout_keep_mask",
+    "dropout_attention_fw",
+    "dropout_attention_bw",
 ]
 
 
@@ -169,6 +172,68 @@ def masked_attention_bw(q, k, v, do, key_mask, causal: bool = False, dtype=np.fl
     o = np.matmul(p, v)
     dv = np.matmul(np.swapaxes(p, -1, -2), do)
     dp = np.matmul(do, np.swapaxes(v, -1, -2))
+    ds = p * (dp - (do * o).sum(axis=-1, keepdims=True))
+    return tau * np.matmul(ds, k), tau * np.matmul(np.swapaxes(ds, -1, -2), q), dv
+
+
+def dropout_keep_mask(BH: int, N: int, rate: float, seed: int) -> np.ndarray:
+    """The HIP path's stateless dropout mask (csrc/fa_atoms.h drop_base / drop_keep) restated in NumPy uint32
+    arithmetic: keep[bh, q, k] = (hash32(seed + bh*0xC2B2AE3D + q*0x9E3779B1 + k*0x85EBCA77) >> 8) >= floor(rate * 2^24),
+    i.e. "rate < r" with r a 24-bit uniform, minitorch's keep rule (minitorch/nn.py:168-186: `drop = rate < r`).
+    The reference applies no dropout on its flash path and draws its masks from NumPy's global RNG elsewhere, so
+    there is nothing bit-level to pin: what IS the reference's is the rule and that the mask multiplies the
+    probabilities (kernel_tests/test_flashattn_fw.py:66,71)."""
+    thr = np.uint32(int(float(np.float32(rate)) * 16777216.0))
+    with np.errstate(over="ignore"):
+        bh = np.arange(BH, dtype=np.uint32)[:, None, None] * np.uint32(0xC2B2AE3D)
+        qq = np.arange(N, dtype=np.uint32)[None, :, None] * np.uint32(0x9E3779B1)
+        kk = np.arange(N, dtype=np.uint32)[None, None, :] * np.uint32(0x85EBCA77)
+        a = (np.uint32(seed & 0xFFFFFFFF) + bh + qq + kk).astype(np.uint32)
+        a ^= a >> np.uint32(16)
+        a *= np.uint32(0x7FEB352D)
+        a ^= a >> np.uint32(15)
+        a *= np.uint32(0x846CA68B)
+        a ^= a >> np.uint32(16)
+    return (a >> np.uint32(8)) >= thr
+
+
+def dropout_attention_fw(q, k, v, keep, scale=1.0, key_mask=None, causal: bool = False, dtype=np.float64):
+    """out = scale * (keep o softmax(tau Q K^T + mask)) V; returns (O, L) with L the log-sum-exp BEFORE dropout.
+    q, k, v: (B, H, N, d); keep: boolean (B*H, N, N) or broadcastable to (B, H, N, N)."""
+    dtype = np.dtype(dtype).type
+    B, H, N, d = q.shape
+    km = np.zeros((B, 1, N)) if key_mask is None else key_mask
+    s = _masked_scores(q, k, km, causal, dtype)
+    m = s.max(axis=-1, keepdims=True)
+    dead = ~np.isfinite(m)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = np.exp(s - np.where(dead, 0.0, m))
+        l = p.sum(axis=-1, keepdims=True)
+        p = np.where(dead, 0.0, p / np.where(dead, 1.0, l))
+        L = np.where(dead[..., 0], -np.inf, m[..., 0] + np.log(np.where(dead, 1.0, l))[..., 0])
+    pd = p * np.asarray(keep).reshape(B, H, N, N) * dtype(scale)
+    return np.matmul(pd, np.asarray(v, dtype=dtype)), L
+
+
+def dropout_attention_bw(q, k, v, do, keep, scale=1.0, key_mask=None, causal: bool = False, dtype=np.float64):
+    """Backward of dropout_attention_fw: dV = (scale M o P)^T dO; dS = P o (scale M o (dO V^T) - rowsum(dO o O));
+    dQ = tau dS K; dK = tau dS^T Q (the tile algebra of kernel_tests/flash_attn_python.py:130-141 with the mask on P)."""
+    dtype = np.dtype(dtype).type
+    q, k, v, do = (np.asarray(x, dtype=dtype) for x in (q, k, v, do))
+    B, H, N, d = q.shape
+    tau = dtype(_tau(d))
+    km = np.zeros((B, 1, N)) if key_mask is None else key_mask
+    s = _masked_scores(q, k, km, causal, dtype)
+    m = s.max(axis=-1, keepdims=True)
+    dead = ~np.isfinite(m)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = np.exp(s - np.where(dead, 0.0, m))
+        p = np.where(dead, 0.0, p / np.where(dead, 1.0, p.sum(axis=-1, keepdims=True)))
+    mk = np.asarray(keep).reshape(B, H, N, N) * dtype(scale)
+    pd = p * mk
+    o = np.matmul(pd, v)
+    dv = np.matmul(np.swapaxes(pd, -1, -2), do)
+    dp = mk * np.matmul(do, np.swapaxes(v, -1, -2))
     ds = p * (dp - (do * o).sum(axis=-1, keepdims=True))
     return tau * np.matmul(ds, k), tau * np.matmul(np.swapaxes(ds, -1, -2), q), dv
 

@@ -309,6 +309,50 @@ def test_key_mask_forward_backward(dev, dtype, d, causal):
     assert maxabs(to_np(oz), to_np(o0)) < tol * 0.5 and maxabs(to_np(lz), to_np(l0)) < tol * 0.5
 
 
+@pytest.mark.parametrize("dtype,d", [("bf16", 64), ("bf16", 128), ("f32", 32)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_dropout_forward_backward(dev, dtype, d, causal):
+    """SURVEY.md row f4, dropout: the in-kernel stateless mask equals the oracle's NumPy restatement bit for bit, so
+    forward and backward match the oracle's dropout attention on the same mask; the three kernels regenerate the SAME
+    mask (dV, dK, dQ consistent with O); with and without a key mask; rate 0 is the masked operator."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    rng = np.random.default_rng(50 + d)
+    B, H, N = 2, 2, 200
+    rate, seed = 0.2, 0xC0FFEE
+    scale = 1.0 / (1.0 - rate)
+    arrs = [rand_u(rng, (B, H, N, d)) for _ in range(4)]
+    if dtype == "bf16":
+        arrs = [oracle.bf16_round(a) for a in arrs]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", tdt) for a in arrs)
+    keep = oracle.dropout_keep_mask(B * H, N, rate, seed)
+    assert 0.75 < keep.mean() < 0.85
+    mask = np.zeros((B, N), dtype=np.float32)
+    mask[1, 160:] = -np.inf
+    tol = (TOLBF_CAUSAL if causal else TOLBF) if dtype == "bf16" else TOL32
+    tol *= scale
+    for km, tkm in ((None, None), (mask, torch.from_numpy(mask).cuda())):
+        okm = None if km is None else km[:, None, :]
+        ro, rL = oracle.dropout_attention_fw(*arrs[:3], keep, scale, okm, causal)
+        rg = oracle.dropout_attention_bw(*arrs, keep, scale, okm, causal)
+        for variant in (_lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2):
+            o, l, m = dev.flash_attn_fwd_dropout(tq, tk, tv, rate, seed, scale, tkm, causal, variant)
+            dq, dk, dv = dev.flash_attn_bwd_dropout(tq, tk, tv, o, tdo, l, m, rate, seed, scale, tkm, causal, variant)
+            L = to_np(m) + np.log(to_np(l)) if variant == _lib.FA_VARIANT_FA1 else to_np(l)
+            assert maxabs(to_np(o), ro) < tol, maxabs(to_np(o), ro)
+            assert maxabs(L, rL) < tol
+            for nm, got, ref in (("dq", dq, rg[0]), ("dk", dk, rg[1]), ("dv", dv, rg[2])):
+                assert maxabs(to_np(got), ref) < tol, (nm, maxabs(to_np(got), ref))
+    # a different seed is a different mask; rate 0 is the plain operator
+    o_a, _, _ = dev.flash_attn_fwd_dropout(tq, tk, tv, rate, seed, scale, None, causal)
+    o_b, _, _ = dev.flash_attn_fwd_dropout(tq, tk, tv, rate, seed + 1, scale, None, causal)
+    assert maxabs(to_np(o_a), to_np(o_b)) > 10 * tol
+    o_0, l_0, _ = dev.flash_attn_fwd_dropout(tq, tk, tv, 0.0, seed, 1.0, None, causal)
+    o_p, l_p, _ = dev.flash_attn_fwd(tq, tk, tv, causal)
+    assert maxabs(to_np(o_0), to_np(o_p)) < tol and maxabs(to_np(l_0), to_np(l_p)) < tol
+
+
 def test_long_sequence(dev):
     """N = 8192 against the oracle on one head, and N = 32768 through size-independent properties (no N^2 memory on
     either side: the reference's only sequence-length limit is time)."""

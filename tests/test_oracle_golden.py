@@ -196,3 +196,38 @@ def test_masked_oracle_reduces_to_pinned_unmasked_oracle():
     g2 = oracle.masked_attention_bw(q, k, v, do, mask2, True)
     assert np.all(o2[:, :, 0] == 0) and np.all(np.isneginf(L2[:, :, 0])) and np.all(np.isfinite(o2))
     assert all(np.all(np.isfinite(g)) for g in g2)
+
+
+def test_dropout_oracle_identities():
+    """Dropout (row f4) has no reference fixture; the oracle is tied to the pinned functions: an all-ones keep matrix is
+    the unmasked operator (the reference's own test multiplies by ones, kernel_tests/test_flashattn_fw.py:66,71), the
+    analytic backward matches finite differences with a fixed 0/1 matrix, and the hash mask keeps ~ (1 - rate)."""
+    rng = np.random.default_rng(12)
+    B, H, N, d = 1, 2, 24, 8
+    q, k, v, do = (rng.uniform(-1, 1, (B, H, N, d)) for _ in range(4))
+    ones = np.ones((B * H, N, N), dtype=bool)
+    for causal in (False, True):
+        o0, L0, _, _ = oracle.dense_attention_fw(q, k, v, causal)
+        o1, L1 = oracle.dropout_attention_fw(q, k, v, ones, 1.0, None, causal)
+        assert np.allclose(o1, o0, atol=1e-13) and np.allclose(L1, L0, atol=1e-13)
+        for a, b in zip(oracle.dropout_attention_bw(q, k, v, do, ones, 1.0, None, causal),
+                        oracle.dense_attention_bw(q, k, v, do, causal)):
+            assert np.allclose(a, b, atol=1e-13)
+    keep = oracle.dropout_keep_mask(B * H, N, 0.3, 1234)
+    scale = 1.0 / 0.7
+    f = lambda q_, k_, v_: float((oracle.dropout_attention_fw(q_, k_, v_, keep, scale, None, True)[0] * do).sum())
+    dq, dk, dv = oracle.dropout_attention_bw(q, k, v, do, keep, scale, None, True)
+    eps = 1e-6
+    for arr, grad, idx in ((q, dq, (0, 1, 5, 3)), (k, dk, (0, 0, 2, 7)), (v, dv, (0, 1, 9, 0))):
+        hi, lo = arr.copy(), arr.copy()
+        hi[idx] += eps
+        lo[idx] -= eps
+        args_hi = [hi if a is arr else a for a in (q, k, v)]
+        args_lo = [lo if a is arr else a for a in (q, k, v)]
+        fd = (f(*args_hi) - f(*args_lo)) / (2 * eps)
+        assert abs(fd - grad[idx]) < 1e-6, (fd, grad[idx])
+    big = oracle.dropout_keep_mask(4, 256, 0.25, 7)
+    assert abs(big.mean() - 0.75) < 0.01
+    assert oracle.dropout_keep_mask(2, 16, 0.0, 3).all()
+    # decorrelated across heads and seeds
+    assert abs((big[0] == big[1]).mean() - (0.75 ** 2 + 0.25 ** 2)) < 0.02
