@@ -92,7 +92,7 @@ def main():
     # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
     # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
     # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
-    slot = args.dtype == "bf16" and d == 64
+    slot = args.dtype == "bf16" and d == 64 and not causal
     K_FWD, K_DQ = ("fwd_slot_kernel", "bwd_dq_slot_kernel") if slot else ("fwd_kernel", "bwd_dq_kernel")
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
               ("bwd_dkdv_kernel", lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
@@ -187,10 +187,18 @@ def main():
                 nh += 1
             ct = time.perf_counter() - c0
         cpu_flops = 14.0 * nh * N * N * d * cf
+        # SURVEY.md section 8d also asks for the one-thread time: one head, one BLAS thread
+        with threadpool_limits(limits=1):
+            c1 = time.perf_counter()
+            oracle.vanilla_attention_fw_bw_f32(hq[0], hk[0], hv[0], hdo[0], causal)
+            ct1 = time.perf_counter() - c1
         cpu_baseline = {"value": round(cpu_flops / ct / 1e12, 5), "unit": "TFLOP/s", "cores": nthreads,
                         "kind": "port",
                         "sample": f"{nh} of {BH} heads of the same workload (NumPy fp32 materialised-S attention fw+bw, "
-                                  f"{nthreads} BLAS threads), {ct:.1f} s"}
+                                  f"{nthreads} BLAS threads), {ct:.1f} s",
+                        "host_cpu_count": os.cpu_count(),
+                        "single_thread": {"value": round(14.0 * N * N * d * cf / ct1 / 1e12, 5), "unit": "TFLOP/s",
+                                          "sample": f"1 head, 1 BLAS thread, {ct1:.1f} s"}}
 
     if rank == 0:
         line = {

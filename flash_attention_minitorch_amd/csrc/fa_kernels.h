@@ -294,28 +294,40 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward, slot-interleaved (bf16, d = 64, FA-2 side output): a workgroup = 8 waves = 256 query rows (two waves per
-// SIMD), query on the lane as above.  K / V arrive by LDS-DMA in stages of 128 keys (three-slot rings, V 48 KiB above
-// K) and are consumed as 32-key sub-tiles by a three-deep software pipeline of MFMA slots (see the dK/dV kernel):
-//   period j = 8 slots:   slots 0-3  S^T(j+1) = K Q^T          slots 4-7  O^T += V^T P^T(j-1)
-// with the fma / exp / add / pack of sub-tile j spread over all eight.  At d = 64 the softmax is 36 issue cycles per
-// slot against the 24 an MFMA leaves free: this kernel is VALU-issue bound by construction, the slots only make the
-// MFMAs disappear under it.  Reference handling as in fwd_kernel: the first sub-tile sets the per-row reference to its
+// Forward, slot-interleaved (bf16, d = 64 or 128, FA-2 side output): a workgroup = 8 waves = 256 query rows (two waves
+// per SIMD), query on the lane as above.  K / V arrive by LDS-DMA in 16 KiB stages (128 keys at d = 64, 64 at d = 128;
+// K and V rings of R slots, V above K) and are consumed as 32-key sub-tiles by a three-deep software pipeline of MFMA
+// slots (see the dK/dV kernel):
+//   period j = 2*KC slots (KC = d/16):   first KC slots  S^T(j+1) = K Q^T        last KC slots  O^T += V^T P^T(j-1)
+// with the fma / exp / add / pack of sub-tile j spread over all of them.  At d = 64 the softmax is 36 issue cycles per
+// slot against the 24 an MFMA leaves free (VALU-issue bound by construction, the slots make the MFMAs disappear under
+// it); at d = 128 it is 18.  Reference handling as in fwd_kernel: the first sub-tile sets the per-row reference to its
 // row maximum; afterwards P is computed against the reference with no maximum, and a lane whose partial row sum
 // reaches 2^6 (rare) makes the wave redo that sub-tile the classic way (scores again from LDS, true maximum,
 // reference moved, O and l rescaled) at the end of its period, before its P.V is issued.
+// Stage hand-off: the barrier that publishes stage s+1 sits NSUBT-2 periods into stage s (the rows of a sub-tile are
+// first requested two periods ahead).  With four sub-tiles per stage (d = 64) the DMA of stage s+1 is issued at the
+// top of stage s into a three-slot ring; with two (d = 128) the barrier is at the top of the stage, the DMA of stage
+// s+2 follows it, and the ring has four slots (a stage's V is still read one period into the next stage).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int DIAG = 0>
+// MASKS = false: the caller guarantees a non-causal launch with N a multiple of the stage (no sub-tile ever needs a mask),
+// which removes the masked period variants and their register pressure at the joins (needed at d = 128).
+template <typename T, int D, bool MASKS = true>
 __global__ void __launch_bounds__(512)
 fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
                 float* __restrict__ aux_l, int N, int nqb, int BH, Layout lay, int causal, float tau) {
-  static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
+  static_assert((D == 64 || D == 128) && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64 / 128");
   using A = Atom<T>;
   typedef typename A::frag frag;
-  constexpr int KC = D / 16, ST = 128;
+  constexpr int KC = D / 16, DT = D / 32, NS = 2 * KC, EPS = 16 / NS;   // slots per period, scores per slot
+  constexpr int ST = 8192 / D;                        // keys per stage: 16 KiB of K and of V
+  constexpr int NSUBT = ST / 32;                      // sub-tiles per stage: 4 (d = 64) or 2 (d = 128)
+  constexpr int R = NSUBT == 2 ? 4 : 3;               // ring slots
   constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB
-  constexpr int VOFF = 3 * TB;
-  __shared__ __attribute__((aligned(16))) char smem_raw[6 * TB];
+  constexpr int VOFF = R * TB;
+  constexpr int SUBB = (D / 32) * 512 * 4;            // bytes of one 32-key sub-tile inside a stage image
+  static_assert(TB == 16384 && 2 * DT == KC, "stage geometry");
+  __shared__ __attribute__((aligned(16))) char smem_raw[2 * R * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -335,9 +347,9 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   frag qf[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
-  f32x16 acc_o[2];
-  acc_o[0] = zero16();
-  acc_o[1] = zero16();
+  f32x16 acc_o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc_o[dt] = zero16();
   float m_ref = 0.f, nmc = 0.f, l_run = 0.f;
 
   const LaneAddr ra = A::template row_addr<D>(lane);
@@ -345,31 +357,38 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   const int kmax = causal ? min(N, qb * 256 + 256) : N;
   const int nstage = (kmax + ST - 1) / ST;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
+  // LDS-DMA pieces of 1 KiB: d = 64: one 8-row group (piece = w, w + 8); d = 128: half of one (piece = 2 * group + half).
+  // The image's chunk swizzle is applied to each lane's SOURCE address; a wave's pieces share its parity, hence one offset.
+  constexpr int PPG = D / 64;   // pieces per 8-row group
   const int dma_row7 = (lane >> 2) & 7;
+  const int dma_gpar = (PPG == 1) ? (w & 1) : ((w >> 1) & 1);
+  const int dma_half = (PPG == 1) ? 0 : (w & 1);
   const int dma_voff = dma_row7 * ld * (int)sizeof(T) +
-                       16 * (4 * (lane >> 5) + ((lane & 3) ^ ((2 * (w & 1) + (dma_row7 >> 2)) & 3)));
+                       16 * (4 * (2 * dma_half + (lane >> 5)) + ((lane & 3) ^ ((2 * dma_gpar + (dma_row7 >> 2)) & 3)));
   auto stage_dma = [&](int row0, int slot_base) {
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-      const int g = w + 8 * g2;
+      const int piece = w + 8 * g2, g = piece / PPG;
       const int soff = (row0 + 8 * g) * ld * (int)sizeof(T);
-      dma16(kraw, smem_addr + slot_base + 1024 * g, dma_voff, soff);
-      dma16(vraw, smem_addr + slot_base + VOFF + 1024 * g, dma_voff, soff);
+      dma16(kraw, smem_addr + slot_base + 1024 * piece, dma_voff, soff);
+      dma16(vraw, smem_addr + slot_base + VOFF + 1024 * piece, dma_voff, soff);
     }
   };
+  auto slot_of = [&](int st) { return (st % R) * TB; };
   stage_dma(0, 0);
+  if (NSUBT == 2 && nstage > 1) stage_dma(ST, slot_of(1));
   dma_wait_all();
   __syncthreads();
 
   f32x16 sA, sB;
   u32x4 pA0, pA1, pB0, pB1;   // packed P^T (bf16 pairs): chunks s2 = 0, 1 of the two sub-tiles in flight
-  frag rk[4], tf[4];
+  frag rk[4], tf[4];          // rings: K rows of the S^T chain, transposed V of the P.V chain (requested two slots ahead)
   auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
   auto krow = [&](int b0, int b1, int sub, int kc) -> frag {
-    return *FA_LDS(frag, smem + ((kc & 1) ? b1 : b0) + (D / 32) * 512 * (4 * sub) + 512 * (kc >> 1));
+    return *FA_LDS(frag, smem + ((kc & 1) ? b1 : b0) + SUBB * sub + 512 * (kc >> 1));
   };
   auto vtr = [&](int b0, int b1, int sub, int s2, int dt) -> frag {
-    const int kk = VOFF + (D / 32) * 512 * (4 * sub + 2 * s2) + 512 * dt;
+    const int kk = VOFF + SUBB * sub + (D / 32) * 512 * (2 * s2) + 512 * dt;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b0 + kk));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b1 + kk + (D / 32) * 512));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -390,16 +409,16 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, x[i]);
     return xhalf_max(mx);
   };
-  // One period.  SUBN / rn*: sub-tile whose S^T is produced; SUBP / tp*: sub-tile whose P.V is issued; SUB2 / r2*: the
-  // sub-tile two ahead (its K rows are requested in slots 6, 7); SUBC / rc* / kcur: the sub-tile in the softmax stream.
+  // One period.  SUBN / rn*: sub-tile whose S^T is produced (its rows 2.. are requested here, rows 0, 1 were requested by
+  // the period before); SUBP / tp*: sub-tile whose P.V is issued; SUB2 / r2*: the sub-tile two ahead (rows 0, 1 requested in
+  // the last two slots); SUBC / rc* / kcur: the sub-tile in the softmax stream.
   auto period = [&](auto hn_c, auto hc_c, auto hp_c, auto mask_c, auto subn_c, auto subp_c, auto sub2_c, auto subc_c,
-                    int tp0, int tp1, int r20, int r21, int rc0, int rc1, int kcur, f32x16& ns, f32x16& cs,
-                    u32x4& pp0, u32x4& pp1, u32x4& pc0, u32x4& pc1) {
+                    int rn0, int rn1, int tp0, int tp1, int r20, int r21, int rc0, int rc1, int kcur, f32x16& ns,
+                    f32x16& cs, u32x4& pp0, u32x4& pp1, u32x4& pc0, u32x4& pc1) {
     constexpr bool HN = decltype(hn_c)::value != 0, HC = decltype(hc_c)::value != 0, HP = decltype(hp_c)::value != 0;
     constexpr bool MASK = decltype(mask_c)::value != 0;
     constexpr int SUBN = decltype(subn_c)::value, SUBP = decltype(subp_c)::value, SUB2 = decltype(sub2_c)::value;
     constexpr int SUBC = decltype(subc_c)::value;
-    (void)SUBN;
     float rs = 0.f, cm = c;
     if constexpr (MASK) {
       asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the two variants' common fma out of the branch
@@ -410,57 +429,64 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       cs[i] = pv;
       rs += pv;
     };
+    // softmax work of slot g: its EPS scores, then the bf16 pack of the pairs completed by the slot before (the last
+    // slot also packs its own)
+    auto valu = [&](int g) {
+      if constexpr (HC) {
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3: S^T of the next sub-tile
+        for (int e = 0; e < EPS; ++e) fe(g * EPS + e);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int done_at = (2 * p + 1) / EPS;   // slot that finishes pair p
+          if (done_at == g - 1 || (g == NS - 1 && done_at == g)) {
+            const uint32_t pk = cvt2(cs[2 * p], cs[2 * p + 1]);
+            if (p < 4) pc0[p] = pk;
+            else pc1[p - 4] = pk;
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int kq = 0; kq < KC; ++kq) {   // S^T of the next sub-tile
       if constexpr (HN) {
         if (kq == 0) A::mma_c(ns, rk[0], qf[0], zero16());
-        else A::mma(ns, rk[kq], qf[kq]);
+        else A::mma(ns, rk[kq & 3], qf[kq]);
         SB();   // the MFMA opens its slot; the fillers follow in its shadow
+        if (kq + 2 < KC) rk[(kq + 2) & 3] = krow(rn0, rn1, SUBN, kq + 2);
       }
-      if constexpr (HC) {
-        fe(2 * kq); fe(2 * kq + 1);
-        if (kq >= 1) pc0[kq - 1] = cvt2(cs[2 * kq - 2], cs[2 * kq - 1]);
-      }
+      valu(kq);
       if constexpr (HP) {
-        if (kq >= 2) tf[kq - 2] = vtr(tp0, tp1, SUBP, 0, kq - 2);
+        if (kq >= KC - 2) tf[kq - (KC - 2)] = vtr(tp0, tp1, SUBP, 0, kq - (KC - 2));
       }
       SB();
     }
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {   // slots 4-7: P.V of the previous sub-tile
+    for (int t = 0; t < KC; ++t) {   // P.V of the previous sub-tile: chunk s2 = t / DT of its keys, columns 32 * (t % DT)
       if constexpr (HP) {
-        A::mma(acc_o[kq & 1], tf[kq], __builtin_bit_cast(frag, (kq < 2) ? pp0 : pp1));
+        A::mma(acc_o[t % DT], tf[t & 3], __builtin_bit_cast(frag, (t < DT) ? pp0 : pp1));
         SB();
-        if (kq < 2) tf[2 + kq] = vtr(tp0, tp1, SUBP, 1, kq);
+        if (t + 2 < KC) tf[(t + 2) & 3] = vtr(tp0, tp1, SUBP, (t + 2) / DT, (t + 2) % DT);
       }
-      if constexpr (HC) {
-        fe(8 + 2 * kq); fe(9 + 2 * kq);
-        if (kq == 0) pc0[3] = cvt2(cs[6], cs[7]);
-        else pc1[kq - 1] = cvt2(cs[6 + 2 * kq], cs[7 + 2 * kq]);
-        if (kq == 3) pc1[3] = cvt2(cs[14], cs[15]);
-      }
+      valu(KC + t);
       if constexpr (HN) {
-        if (kq >= 2) {
-          rk[2 * (kq - 2)] = krow(r20, r21, SUB2, 2 * (kq - 2));
-          rk[2 * (kq - 2) + 1] = krow(r20, r21, SUB2, 2 * (kq - 2) + 1);
-        }
+        if (t >= KC - 2) rk[t - (KC - 2)] = krow(r20, r21, SUB2, t - (KC - 2));
       }
       SB();
     }
     if constexpr (HC) {
       float alpha = 1.0f;
       if (__any(!(rs < MAX_DEFER_SUM))) {   // rare: some row outgrew its reference -> redo this sub-tile the classic way
-        frag kk[4];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) kk[kc] = krow(rc0, rc1, SUBC, kc);
-        A::mma_c(cs, kk[0], qf[0], zero16());
-#pragma unroll
-        for (int kc = 1; kc < 4; ++kc) A::mma(cs, kk[kc], qf[kc]);
+        for (int kc = 0; kc < KC; ++kc) {
+          const frag kk = krow(rc0, rc1, SUBC, kc);
+          if (kc == 0) A::mma_c(cs, kk, qf[0], zero16());
+          else A::mma(cs, kk, qf[kc]);
+        }
         if constexpr (MASK) mask_scores(cs, kcur);
         const float delta = fmaxf(tile_max(cs) - m_ref, 0.f);
         alpha = __builtin_amdgcn_exp2f(-delta * c);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
         m_ref += delta;
@@ -482,57 +508,94 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   };
   auto T1 = ic<1>{};
   auto T0 = ic<0>{};
-  auto slot_of = [&](int st) { return (st % 3) * TB; };
-  int cr0 = ra.b[0], cr1 = ra.b[1];
-  int ct0 = ta.b[0], ct1 = ta.b[1];
-  int pt0 = ct0, pt1 = ct1;
+  int cr0 = ra.b[0], cr1 = ra.b[1];   // row addresses of the current stage (slot 0)
+  int ct0 = ta.b[0], ct1 = ta.b[1];   // transposed-read addresses of the current stage
+  int pt0 = ct0, pt1 = ct1;           // ... of the previous stage (stage 0: any finite data, P = 0)
   // prologue: S^T of sub-tile 0, whose row maximum becomes the reference
-#pragma unroll
-  for (int kc = 0; kc < 4; ++kc) rk[kc] = krow(cr0, cr1, 0, kc);
+  rk[0] = krow(cr0, cr1, 0, 0);
+  rk[1] = krow(cr0, cr1, 0, 1);
   pB0 = pB1 = pA0 = pA1 = u32x4{0u, 0u, 0u, 0u};
   SB();
-  period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, ic<0>{}, ct0, ct1, cr0, cr1, cr0, cr1, 0, sA, sB, pB0, pB1, pA0, pA1);
+  period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, 0, sA, sB, pB0, pB1, pA0, pA1);
   {
-    const bool m0 = (31 >= N) || (causal && 31 > q0);
+    const bool m0 = MASKS && ((31 >= N) || (causal && 31 > q0));
     if (m0) mask_scores(sA, 0);
     m_ref = tile_max(sA);      // key 0 is never masked, so the maximum is finite
     nmc = -m_ref * c;
   }
   for (int st = 0; st < nstage; ++st) {
-    const bool more = st + 1 < nstage;
     const int nb = slot_of(st + 1);
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;
-    if (more) stage_dma((st + 1) * ST, nb);
     const int kb = st * ST;
-    // sub-tile 0 of stage 0 was masked in the prologue already (masking twice is harmless)
-    auto need = [&](int sub) { return (kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0); };
-    // period 4st+0: produce sub 1, softmax of sub 0, P.V of sub 3 of the previous stage
-    if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
-    else         period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
-    // period 4st+1: produce sub 2, softmax of sub 1, P.V of sub 0
-    if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
-    else         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
-    dma_wait_all();   // this wave's pieces of the next stage have landed
-    __syncthreads();
-    // period 4st+2: produce sub 3, softmax of sub 2, P.V of sub 1; rows two ahead = sub 0 of the next stage
-    if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
-    else         period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
-    // period 4st+3: produce sub 0 of the next stage, softmax of sub 3, P.V of sub 2
-    if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
-    else         period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
+    // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
+    auto need = [&](int sub) { return MASKS && ((kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0)); };
+    if constexpr (NSUBT == 4) {
+      if (st + 1 < nstage) stage_dma((st + 1) * ST, nb);
+      // period 4st+0: produce sub 1, softmax of sub 0, P.V of sub 3 of the previous stage
+      if constexpr (MASKS) {
+        if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+        else period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+      } else {
+        period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+      }
+      // period 4st+1: produce sub 2, softmax of sub 1, P.V of sub 0
+      if constexpr (MASKS) {
+        if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+        else period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+      } else {
+        period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+      }
+      dma_wait_all();   // this wave's pieces of the next stage have landed
+      __syncthreads();
+      // period 4st+2: produce sub 3, softmax of sub 2, P.V of sub 1; rows two ahead = sub 0 of the next stage
+      if constexpr (MASKS) {
+        if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
+        else period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
+      } else {
+        period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
+      }
+      // period 4st+3: produce sub 0 of the next stage, softmax of sub 3, P.V of sub 2
+      if constexpr (MASKS) {
+        if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, nr0, nr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
+        else period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, nr0, nr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
+      } else {
+        period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, ic<3>{}, nr0, nr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 96, sA, sB, pA0, pA1, pB0, pB1);
+      }
+    } else {
+      // two sub-tiles per stage: stage st+1 (requested one stage ago) is published here, then stage st+2 is requested
+      if (st > 0) {   // (stage 1 was waited for and published in the prologue)
+        dma_wait_all();
+        __syncthreads();
+      }
+      if (st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));
+      // period 2st+0: produce sub 1, softmax of sub 0, P.V of sub 1 of the previous stage; rows two ahead: next stage, sub 0
+      if constexpr (MASKS) {
+        if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, nr0, nr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+        else period(T1, T1, T1, T0, ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, nr0, nr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+      } else {
+        period(T1, T1, T1, T0, ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, nr0, nr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
+      }
+      // period 2st+1: produce sub 0 of the next stage, softmax of sub 1, P.V of sub 0; rows two ahead: next stage, sub 1
+      if constexpr (MASKS) {
+        if (need(1)) period(T1, T1, T1, T1, ic<0>{}, ic<0>{}, ic<1>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+        else period(T1, T1, T1, T0, ic<0>{}, ic<0>{}, ic<1>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+      } else {
+        period(T1, T1, T1, T0, ic<0>{}, ic<0>{}, ic<1>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
+      }
+    }
     pt0 = ct0; pt1 = ct1;
     cr0 = nr0; cr1 = nr1;
     ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
   }
-  // drain: P.V of the last sub-tile
-  period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, ic<0>{}, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
+  // drain: P.V of the last sub-tile (the buffers alternate per sub-tile: an even count per stage ends on B)
+  period(T0, T0, T1, T0, ic<0>{}, ic<NSUBT - 1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
 
   const float l_tot = xhalf_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (qvalid) {
     float* orow = o + base + (size_t)qrow * ld;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 val = {acc_o[dt][4 * g] * inv, acc_o[dt][4 * g + 1] * inv, acc_o[dt][4 * g + 2] * inv,
@@ -1234,7 +1297,9 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // stage, hence the third ring slot.  Whole stages are always processed; sub-tiles beyond the causal diagonal or
 // N are masked (P = 0).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int DIAG = 0>
+// MASKS = false: non-causal launch with N a multiple of 128 (no sub-tile ever needs a mask): the masked period variants and
+// their register pressure at the joins disappear.
+template <typename T, int D, int DIAG = 0, bool MASKS = true>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                    const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
@@ -1348,57 +1413,76 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     auto vrow = [&](int kq) -> frag {
       return *FA_LDS(frag, smem + ((kq & 1) ? rn1 : rn0) + VOFF + (D / 32) * 512 * (4 * SUBN) + 512 * (kq >> 1));
     };
-    // fragments are requested two slots before the MFMA that consumes them (K rows of the next period: slots 10, 11)
+    // LDS fragments are requested LEAD slots before the MFMA that consumes them: 4 in the build without masked periods
+    // (186 VGPRs), 2 where the masked variants' joins leave no registers for more
+    constexpr int LEAD = MASKS ? 2 : 4;
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3
+    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3: S^T of the next sub-tile
       if constexpr (HN) {
         if (kq == 0) A::mma_c(ns, rk[0], qf[0], zero16());
         else A::mma(ns, rk[kq], qf[kq]);
         SB();   // the MFMA opens its slot; the fillers follow in its shadow
-        if (kq >= 2) rv[kq - 2] = vrow(kq - 2);
+        if constexpr (LEAD == 4) rv[kq] = vrow(kq);
+        else if (kq >= 2) rv[kq - 2] = vrow(kq - 2);
       }
       if constexpr (HC) { fe(2 * kq); fe(2 * kq + 1); }
       SB();
     }
-    // slot 4
-    if constexpr (HN) { A::mma_c(ndp, rv[0], dof[0], nd16); SB(); rv[2] = vrow(2); }
-    if constexpr (HC) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) md(i);
-    }
-    SB();
-    // slot 5
-    if constexpr (HN) { A::mma(ndp, rv[1], dof[1]); SB(); rv[3] = vrow(3); }
-    if constexpr (HC) { md(6); md(7); dc0 = A::pack(cdp, 0); }
-    SB();
-    // slots 6, 7
+    for (int kq = 0; kq < 4; ++kq) {   // slots 4-7: dP^T of the next sub-tile
+      if constexpr (HN) {
+        if (kq == 0) A::mma_c(ndp, rv[0], dof[0], nd16);
+        else A::mma(ndp, rv[kq], dof[kq]);
+        SB();
+        if constexpr (LEAD == 2) {
+          if (kq < 2) rv[kq + 2] = vrow(kq + 2);
+        }
+      }
+      if constexpr (HC) {
+        if (kq == 0) {
 #pragma unroll
-    for (int kq = 2; kq < 4; ++kq) {
-      if constexpr (HN) { A::mma(ndp, rv[kq], dof[kq]); SB(); }
-      if constexpr (HC) { fe(4 + 2 * kq); fe(5 + 2 * kq); }
-      if constexpr (HP) tf[kq - 2] = ktr(tp0, tp1, SUBP, 0, kq & 1);
+          for (int i = 0; i < 6; ++i) md(i);
+        } else if (kq == 1) {
+          md(6); md(7); dc0 = A::pack(cdp, 0);
+        } else {
+          fe(4 + 2 * kq); fe(5 + 2 * kq);
+        }
+      }
+      if constexpr (HP) {
+        if constexpr (LEAD == 4) tf[kq] = ktr(tp0, tp1, SUBP, kq >> 1, kq & 1);
+        else if (kq >= 2) tf[kq - 2] = ktr(tp0, tp1, SUBP, 0, kq & 1);
+      }
       SB();
     }
-    // slots 8, 9
 #pragma unroll
-    for (int kq = 0; kq < 2; ++kq) {
-      if constexpr (HP) { A::mma(acc[kq], tf[kq], dp0); SB(); tf[2 + kq] = ktr(tp0, tp1, SUBP, 1, kq); }
-      if constexpr (HC) { fe(12 + 2 * kq); fe(13 + 2 * kq); }
+    for (int kq = 0; kq < 4; ++kq) {   // slots 8-11: dQ^T of the previous sub-tile
+      if constexpr (HP) {
+        A::mma(acc[kq & 1], tf[kq], (kq < 2) ? dp0 : dp1);
+        SB();
+        if constexpr (LEAD == 2) {
+          if (kq < 2) tf[2 + kq] = ktr(tp0, tp1, SUBP, 1, kq);
+        }
+      }
+      if constexpr (HC) {
+        if (kq < 2) {
+          fe(12 + 2 * kq); fe(13 + 2 * kq);
+        } else if (kq == 2) {
+#pragma unroll
+          for (int i = 8; i < 14; ++i) md(i);
+        } else {
+          md(14); md(15); dc1 = A::pack(cdp, 1);
+        }
+      }
+      if constexpr (HN) {
+        if constexpr (LEAD == 4) {
+          rk[kq] = krow(r20, r21, SUB2, kq);
+        } else if (kq >= 2) {
+          rk[2 * (kq - 2)] = krow(r20, r21, SUB2, 2 * (kq - 2));
+          rk[2 * (kq - 2) + 1] = krow(r20, r21, SUB2, 2 * (kq - 2) + 1);
+        }
+      }
       SB();
     }
-    // slot 10
-    if constexpr (HP) { A::mma(acc[0], tf[2], dp1); SB(); }
-    if constexpr (HC) {
-#pragma unroll
-      for (int i = 8; i < 14; ++i) md(i);
-    }
-    if constexpr (HN) { rk[0] = krow(r20, r21, SUB2, 0); rk[1] = krow(r20, r21, SUB2, 1); }
-    SB();
-    // slot 11
-    if constexpr (HP) { A::mma(acc[1], tf[3], dp1); SB(); }
-    if constexpr (HC) { md(14); md(15); dc1 = A::pack(cdp, 1); }
-    if constexpr (HN) { rk[2] = krow(r20, r21, SUB2, 2); rk[3] = krow(r20, r21, SUB2, 3); }
-    SB();
   };
   auto T1 = ic<1>{};
   auto T0 = ic<0>{};
@@ -1421,13 +1505,21 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     if (more) stage_dma((st + 1) * ST, nb);
     const int kb = st * ST;
     // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
-    auto need = [&](int sub) { return (kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0); };
+    auto need = [&](int sub) { return MASKS && ((kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0)); };
     // period 4st+0: produce sub 1 (this stage), consume sub 0, dQ of sub 3 of the previous stage
-    if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
-    else         period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    if constexpr (MASKS) {
+      if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+      else period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    } else {
+      period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    }
     // period 4st+1: produce sub 2, consume sub 1, dQ of sub 0
-    if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
-    else         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    if constexpr (MASKS) {
+      if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+      else period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    } else {
+      period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    }
     // the next stage goes to LDS and is published before the second half of period 4st+2 asks for its rows
     if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; }
     dma_wait_all();   // this wave's pieces of the next stage have landed
@@ -1435,11 +1527,19 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
     if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
     // period 4st+2: produce sub 3, consume sub 2, dQ of sub 1; rows two ahead = sub 0 of the next stage
-    if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
-    else         period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    if constexpr (MASKS) {
+      if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+      else period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    } else {
+      period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    }
     // period 4st+3: produce sub 0 of the next stage, consume sub 3, dQ of sub 2
-    if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
-    else         period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    if constexpr (MASKS) {
+      if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+      else period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    } else {
+      period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    }
     pt0 = ct0; pt1 = ct1;
     cr0 = nr0; cr1 = nr1;
     ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;

@@ -151,9 +151,10 @@ const char* fa_mi355x_version(void);
 /* Tuning hook (in-process A/B benchmarks and tests only; every setting computes the same function).
  * key 0: dK/dV kernel, bf16 d <= 64 (0 default: slot-interleaved fast path at d = 64; 4 compiler-interleaved software
  *        pipeline; 1 plain; 2 four waves x 64 keys; 9 / 93 diagnostic builds with phase stamps, never timed)
- * key 1: forward, bf16 d = 64, FA-2 side output (0 default: slot-interleaved kernel; 2 phased kernel)
- * key 2: dQ, bf16 (0 default: slot-interleaved kernel at d = 64, else 32-key tiles; 1 = 64-key tiles; 2 = 32-key
- *        tiles, phased kernel; 93 diagnostic build with phase stamps).  Other keys are reserved. */
+ * key 1: forward, bf16 d = 64, FA-2 side output (0 default: slot-interleaved kernel, phased under the causal mask;
+ *        2 always phased; 3 always slot)
+ * key 2: dQ, bf16 (0 default: slot-interleaved kernel at d = 64 non-causal, else 32-key tiles; 1 = 64-key tiles; 2 = 32-key
+ *        tiles, phased kernel; 3 always slot; 93 / 94 diagnostic builds, never timed).  Other keys are reserved. */
 int fa_mi355x_set_tuning(int key, int value);
 
 /* Profiling hook: per-wave cycle totals per loop phase written by a DIAGNOSTIC build (tuning key 0 = 9 / 93, key 2 = 93);

@@ -244,7 +244,7 @@ def test_slot_kernels_block_and_ring_boundaries(dev, N, causal):
     core = _lib.core()
     try:
         outs = {}
-        for tag, knobs in (("slot", (0, 0, 0)), ("phased", (4, 2, 2))):
+        for tag, knobs in (("slot", (0, 3, 3)), ("phased", (4, 2, 2))):   # 3 forces the slot kernels under the causal mask too
             for key, val in zip((0, 1, 2), knobs):
                 core.fa_mi355x_set_tuning(key, val)
             o, l, m = dev.flash_attn_fwd(tq, tk, tv, causal=causal)
