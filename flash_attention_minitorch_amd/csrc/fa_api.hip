@@ -62,6 +62,12 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
     if (variant == FA_VARIANT_FA2 && g_tuning[1] != 2 && (!causal || g_tuning[1] == 3) && !lay.kmask && !lay.drop_thr) {
       const int nqb = (N + 255) / 256;
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
+      if (whole && g_tuning[1] == 93 && D == 64) {   // phase stamps (never timed)
+        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 1>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
+        FA_HIP_TRY(hipGetLastError());
+        return FA_OK;
+      }
       if (whole) {
         hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);

@@ -312,7 +312,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 // ---------------------------------------------------------------------------------------------
 // MASKS = false: the caller guarantees a non-causal launch with N a multiple of the stage (no sub-tile ever needs a mask),
 // which removes the masked period variants and their register pressure at the joins (needed at d = 128).
-template <typename T, int D, bool MASKS = true>
+template <typename T, int D, bool MASKS = true, int DIAG = 0>
 __global__ void __launch_bounds__(512)
 fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
                 float* __restrict__ aux_l, int N, int nqb, int BH, Layout lay, int causal, float tau) {
@@ -375,10 +375,16 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     }
   };
   auto slot_of = [&](int st) { return (st % R) * TB; };
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
+  if constexpr (DIAG) {
+    k_t0 = stamp();
+    k_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   stage_dma(0, 0);
   if (NSUBT == 2 && nstage > 1) stage_dma(ST, slot_of(1));
   dma_wait_all();
   __syncthreads();
+  if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
   f32x16 sA, sB;
   u32x4 pA0, pA1, pB0, pB1;   // packed P^T (bf16 pairs): chunks s2 = 0, 1 of the two sub-tiles in flight
@@ -545,8 +551,11 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       } else {
         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
       }
+      if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
       dma_wait_all();   // this wave's pieces of the next stage have landed
+      if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
       __syncthreads();
+      if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
       // period 4st+2: produce sub 3, softmax of sub 2, P.V of sub 1; rows two ahead = sub 0 of the next stage
       if constexpr (MASKS) {
         if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
@@ -590,6 +599,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   // drain: P.V of the last sub-tile (the buffers alternate per sub-tile: an even count per stage ends on B)
   period(T0, T0, T1, T0, ic<0>{}, ic<NSUBT - 1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
 
+  if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
   const float l_tot = xhalf_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (qvalid) {
@@ -603,6 +613,17 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = val;
       }
     if (h == 0) aux_l[(size_t)bh * N + qrow] = m_ref * tau + __logf(l_tot);
+  }
+  if constexpr (DIAG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
+    ph[4] += k_t1 - t0;   // epilogue: O / L stores
+    const int slot = blockIdx.x * 8 + w;
+    if (slot < 8192 && lane == 0) {
+      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
+      g_phase_cycles[slot * 8 + 6] = k_t1 - k_t0;
+      g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
+    }
   }
 }
 

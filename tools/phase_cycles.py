@@ -14,9 +14,12 @@ o, L, _ = device_ops.flash_attn_fwd(q, k, v)
 core = _lib.core()
 core.fa_mi355x_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
 MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-KEY = 2 if MODE == 293 else 0          # 293: the slot-interleaved dQ kernel's stamps
-core.fa_mi355x_set_tuning(KEY, 93 if MODE == 293 else MODE)
+KEY = 2 if MODE == 293 else (1 if MODE == 193 else 0)   # 293 / 193: the slot-interleaved dQ / forward kernel's stamps
+core.fa_mi355x_set_tuning(KEY, 93 if MODE in (293, 193) else MODE)
 for _ in range(3):
+    if KEY == 1:
+        device_ops.flash_attn_fwd(q, k, v)
+        continue
     device_ops.flash_attn_bwd(q, k, v, o, do, L, stages=device_ops.STAGE_PREP | (device_ops.STAGE_DQ if KEY == 2 else device_ops.STAGE_DKDV))
 torch.cuda.synchronize()
 buf = np.zeros(8 * 8192, dtype=np.uint64)
@@ -29,7 +32,10 @@ life, real = allc[:, 6], allc[:, 7]
 ok = real > 0
 print("in-kernel clock GHz (median over waves):", round(float(np.median(life[ok] / real[ok])) * 0.1, 3),
       " wave lifetime cycles:", np.median(life[ok]), " stamped cycles:", np.median(tot))
-if MODE == 293:
+if MODE == 193:
+    names = ["prologue (Q load, first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier",
+             "epilogue (normalise, store O and L)", "-"]
+elif MODE == 293:
     names = ["prologue (first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier", "-", "-"]
 elif MODE == 93:
     names = ["stage_load issue", "prologue period (8 MFMA: S,dP of sub 0)", "periods 1-3 (48 MFMA + VALU)",
