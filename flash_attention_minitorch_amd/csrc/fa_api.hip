@@ -163,7 +163,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 8, 128, 93>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 9)   // phased path with phase stamps (never timed)
         rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else   // d = 64 default: slot-interleaved fast path (MFMA slots with pinned VALU / LDS fillers)
+      else   // d = 64 default: slot-interleaved fast path for unmasked stages, per-sub-slice path on the causal diagonal
+        // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
         rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {
       if (g_tuning[0] == 1)
