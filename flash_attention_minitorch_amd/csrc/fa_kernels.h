@@ -380,6 +380,12 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
   }
+  if constexpr (MASKS) {   // ragged launches read stage rows past N: make sure they are zeros whatever an out-of-range
+    // LDS-DMA lane does (0 * stale NaN bits would poison P.V); 96 / 128 KiB once per workgroup
+#pragma unroll 4
+    for (int off = tid * 16; off < 2 * R * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   stage_dma(0, 0);
   if (NSUBT == 2 && nstage > 1) stage_dma(ST, slot_of(1));
   dma_wait_all();
@@ -1391,6 +1397,11 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   if constexpr (DIAG == 1) {
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  if constexpr (MASKS) {   // see fwd_slot_kernel: stage rows past N must read as zeros
+#pragma unroll 4
+    for (int off = tid * 16; off < 6 * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
   }
   stage_dma(0, 0);
   dma_wait_all();   // this wave's pieces have landed

@@ -353,6 +353,32 @@ def test_dropout_forward_backward(dev, dtype, d, causal):
     assert maxabs(to_np(o_0), to_np(o_p)) < tol and maxabs(to_np(l_0), to_np(l_p)) < tol
 
 
+@pytest.mark.parametrize("N", [64, 192, 320, 1024])
+def test_forward_slot_kernel_d128(dev, N):
+    """bf16, d = 128, FA-2, non-causal, N a multiple of its 64-key stage: the slot-interleaved forward (two sub-tiles
+    per stage, four-slot ring, barrier at the top of the stage) against the phased kernel and the oracle; 1, 3, 5 and 16
+    stages exercise the prologue's double DMA, the ring wrapping and the 256-query workgroup edge."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    rng = np.random.default_rng(8000 + N)
+    BH, d = 3, 128
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(3)]
+    tq, tk, tv = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    ro, rL, _, _ = oracle.dense_attention_fw(*arrs)
+    core = _lib.core()
+    try:
+        core.fa_mi355x_set_tuning(1, 0)
+        o_s, l_s, _ = dev.flash_attn_fwd(tq, tk, tv)
+        core.fa_mi355x_set_tuning(1, 2)
+        o_p, l_p, _ = dev.flash_attn_fwd(tq, tk, tv)
+    finally:
+        core.fa_mi355x_set_tuning(1, 0)
+    assert maxabs(to_np(o_s), ro) < TOLBF and maxabs(to_np(l_s), rL) < TOLBF
+    # the two kernels set their softmax reference on 32 vs 64 keys, so P is rounded to bf16 at different scales:
+    # each is within TOLBF of the oracle, their difference within the sum
+    assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF
+
+
 def test_long_sequence(dev):
     """N = 8192 against the oracle on one head, and N = 32768 through size-independent properties (no N^2 memory on
     either side: the reference's only sequence-length limit is time)."""
