@@ -92,8 +92,9 @@ def main():
     # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
     # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
     # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
-    slot = args.dtype == "bf16" and d == 64 and not causal
-    K_FWD, K_DQ = ("fwd_slot_kernel", "bwd_dq_slot_kernel") if slot else ("fwd_kernel", "bwd_dq_kernel")
+    bf = args.dtype == "bf16" and not causal
+    K_FWD = "fwd_slot_kernel" if bf and ((d == 64) or (d == 128 and N % 64 == 0)) else "fwd_kernel"
+    K_DQ = "bwd_dq_slot_kernel" if bf and d == 64 else "bwd_dq_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
               ("bwd_dkdv_kernel", lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
     breakdown = not args.no_kernel_breakdown

@@ -732,13 +732,39 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   const LaneAddr ta = A::template tr_addr<D>(lane);
   const int nqi = (N + QS - 1) / QS;
   const int qi_begin = causal ? (kb0 / QS) : 0;  // query slices entirely above the key block are fully masked
+  // Stage copies of Q and dO.  bf16, d >= 64: LDS-DMA, 1 KiB pieces (half an 8-row group at d = 128), the image's chunk swizzle
+  // applied to each lane's source address; wave w moves pieces w, w + NW, ... (same swizzle parity, one lane offset) -- no
+  // staging registers, no ds_write pass.  Otherwise (fp32's padded image, d = 32): registers, written after the MFMA phase.
+  constexpr bool DMA = sizeof(T) == 2 && D >= 64 && MODE != 9;
+  constexpr int PPG = D >= 128 ? 2 : 1;                          // pieces per 8-row group
+  constexpr int NP = QS * D * (int)sizeof(T) / 1024, NPW = DMA ? NP / NW : 0;
+  static_assert(!DMA || (NP % NW == 0 && NW % 4 == 0), "every wave moves whole pieces of one swizzle parity");
   TileStager<T, D, QS, NT> sq, sdo;
-  sq.init(tid, ld);
-  sdo.init(tid, ld);
+  if constexpr (!DMA) {
+    sq.init(tid, ld);
+    sdo.init(tid, ld);
+  }
+  const raw_rsrc_t qraw = make_raw_rsrc(q + base, mat_bytes), doraw = make_raw_rsrc(dout + base, mat_bytes);
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
+  const int dma_row7 = (lane >> 2) & 7;
+  const int dma_gpar = (PPG == 1) ? (w & 1) : ((w >> 1) & 1);
+  const int dma_half = (PPG == 1) ? 0 : (w & 1);
+  const int dma_voff = dma_row7 * ld * (int)sizeof(T) +
+                       16 * (4 * (2 * dma_half + (lane >> 5)) + ((lane & 3) ^ ((2 * dma_gpar + (dma_row7 >> 2)) & 3)));
   float st_nl = 0.f, st_de = 0.f;
-  auto stage_load = [&](int qi) {
-    sq.load(qrs, qi * QS);
-    sdo.load(dors, qi * QS);
+  auto stage_load = [&](int qi, int dst /* LDS byte offset of the stage buffer */) {
+    if constexpr (DMA) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        const int piece = w + NW * i, g = piece / PPG;
+        const int soff = (qi * QS + 8 * g) * ld * (int)sizeof(T);
+        dma16(qraw, smem_addr + dst + 1024 * piece, dma_voff, soff);
+        dma16(doraw, smem_addr + dst + TB + 1024 * piece, dma_voff, soff);
+      }
+    } else {
+      sq.load(qrs, qi * QS);
+      sdo.load(dors, qi * QS);
+    }
     if (tid < QS) {
       const int row = qi * QS + tid;
       st_nl = row < N ? nlg[row] : 0.f;
@@ -746,15 +772,19 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     }
   };
   auto stage_store = [&](lds_char* b) {
-    sq.store(b);
-    sdo.store(b + TB);
+    if constexpr (DMA) {
+      dma_wait_all();   // this wave's pieces have landed (the barrier that follows publishes them)
+    } else {
+      sq.store(b);
+      sdo.store(b + TB);
+    }
     if (tid < QS) {
       *FA_LDS(float, b + 2 * TB + 4 * tid) = st_nl;
       *FA_LDS(float, b + 2 * TB + 4 * QS + 4 * tid) = st_de;
     }
   };
   if (qi_begin < nqi) {
-    stage_load(qi_begin);
+    stage_load(qi_begin, 0);
     stage_store(smem);
   }
   __syncthreads();
@@ -771,7 +801,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     const bool more = qi + 1 < nqi;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if constexpr (DIAG) t0 = stamp();
-    if (more) stage_load(qi + 1);
+    if (more) stage_load(qi + 1, (PAR ^ 1) * BUF);
     if constexpr (DIAG) { t1 = stamp(); ph[0] += t1 - t0; }
     lds_char* buf = smem + PAR * BUF;
     lds_char* tq = buf;
