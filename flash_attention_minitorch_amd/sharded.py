@@ -78,6 +78,40 @@ def sharded_flash_attn2_fwd(q_local, k_local, v_local, bh_total: int, causal: bo
     return all_gather_bh(o, bh_total, group), all_gather_bh(L, bh_total, group)
 
 
+def sharded_flash_attn2_fwd_overlapped(q_local, k_local, v_local, bh_total: int, causal: bool = False, chunks: int = 4,
+                                       group=None, compute_fn: Optional[Callable] = None):
+    """The same result as sharded_flash_attn2_fwd(..., gather=True) with the all-gather hidden under the compute
+    (at the 8-GPU config the gather of one rank's 256 MiB slice over its xGMI links costs about as
+    much as its forward).  The local slice is cut into ``chunks`` pieces along batch*head; the gather of piece c is issued
+    asynchronously (RCCL runs it on its own stream, ordered after the kernels already queued) and overlaps the kernels
+    of piece c+1; each piece lands directly at its final rows of the [bh_total, ...] outputs, so there is no reshuffle.
+    Needs an even split (bh_total divisible by the world size, the local slice by ``chunks``); otherwise it falls back
+    to the one-shot gather."""
+    fn = compute_fn or _default_fwd
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(bh_total, world)
+    bh_local = q_local.shape[0]
+    if len({e - b for b, e in bounds}) != 1 or chunks <= 1 or bh_local % chunks != 0:
+        return sharded_flash_attn2_fwd(q_local, k_local, v_local, bh_total, causal, True, group, compute_fn)
+    cs = bh_local // chunks
+    o_full = L_full = None
+    pending, keep = [], []
+    for c in range(chunks):
+        sl = slice(c * cs, (c + 1) * cs)
+        o_c, L_c = fn(q_local[sl], k_local[sl], v_local[sl], causal)
+        o_c, L_c = o_c.contiguous(), L_c.contiguous()
+        if o_full is None:
+            o_full = torch.empty((bh_total,) + tuple(o_c.shape[1:]), dtype=o_c.dtype, device=o_c.device)
+            L_full = torch.empty((bh_total,) + tuple(L_c.shape[1:]), dtype=L_c.dtype, device=L_c.device)
+        rows = [slice(b + c * cs, b + (c + 1) * cs) for b, _ in bounds]
+        pending.append(dist.all_gather([o_full[r] for r in rows], o_c, group=group, async_op=True))
+        pending.append(dist.all_gather([L_full[r] for r in rows], L_c, group=group, async_op=True))
+        keep.append((o_c, L_c))   # the pieces must outlive their collectives
+    for work in pending:
+        work.wait()
+    return o_full, L_full
+
+
 def sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_local, bh_total: int,
                             causal: bool = False, gather: bool = True, group=None,
                             compute_fn: Optional[Callable] = None):
