@@ -173,6 +173,19 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else
         rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+    } else if constexpr (D == 64) {
+      // fp32, d = 64 (configs[1], [2]): the allocation lands on 256 VGPRs + 2 AGPRs = one wave per SIMD; asking for two
+      // (launch bound) keeps it under 256 (tuning key 0 = 1: the unconstrained build)
+      if (g_tuning[0] == 1 || lay.drop_thr)
+        rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      else {
+        const int nkb = (N + 127) / 128;
+        hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 4, 32, 0, false, 2>), dim3(batch * nkb), dim3(256), 0, st,
+                           (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
+                           causal, tau);
+        FA_HIP_TRY(hipGetLastError());
+        rc = FA_OK;
+      }
     } else {
       rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     }

@@ -673,8 +673,8 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 // the dK^T, dV^T accumulators of its KPW keys in registers while the workgroup sweeps 32-row query slices
 // (Q, dO tiles + their nlc, delta staged in LDS, double buffered).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false>
-__global__ void __launch_bounds__(NW * 64)
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false, int MINW = 1>
+__global__ void __launch_bounds__(NW * 64, MINW)   // MINW: minimum waves per SIMD the register allocation must allow
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
                 float* __restrict__ dv, int N, int nkb, int BH, Layout lay, int causal, float tau) {
