@@ -379,6 +379,32 @@ def test_forward_slot_kernel_d128(dev, N):
     assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF
 
 
+def test_random_shapes_bf16(dev):
+    """Seeded sweep over sequence lengths that straddle every structural size of the bf16 kernels (32-key sub-tiles, 64 / 128
+    key stages, 128 / 256 query workgroups, 3 / 4 slot rings), head dims, causal flag and batch*head counts that do and do
+    not divide by the 8 XCDs -- whichever kernel the dispatcher picks (slot, masked-slot or phased) must meet the bf16 bound."""
+    import torch
+    rng = np.random.default_rng(20261004)
+    cases = []
+    for _ in range(28):
+        d = int(rng.choice([32, 64, 64, 64, 128, 128]))
+        N = int(rng.choice([rng.integers(1, 70), rng.integers(100, 300), 64 * rng.integers(1, 9), 128 * rng.integers(1, 6),
+                            rng.integers(300, 700)]))
+        cases.append((N, d, bool(rng.integers(0, 2)), int(rng.choice([1, 3, 8, 16]))))
+    for N, d, causal, BH in cases:
+        arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+        tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+        o, L, _ = dev.flash_attn_fwd(tq, tk, tv, causal)
+        dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, L, None, causal)
+        heads = range(min(BH, 3))
+        ref = oracle_heads(*arrs, causal, heads)
+        tol = TOLBF_CAUSAL if causal else TOLBF
+        for nm, got in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
+            g = to_np(got)[: len(heads)]
+            assert np.all(np.isfinite(to_np(got))), (N, d, causal, BH, nm)
+            assert maxabs(g, ref[nm]) < tol, (N, d, causal, BH, nm, maxabs(g, ref[nm]))
+
+
 def test_long_sequence(dev):
     """N = 8192 against the oracle on one head, and N = 32768 through size-independent properties (no N^2 memory on
     either side: the reference's only sequence-length limit is time)."""
