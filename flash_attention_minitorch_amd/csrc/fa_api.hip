@@ -159,6 +159,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 4 || D != 64)   // compiler-interleaved software pipeline (the d = 32 default)
         rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      else if (g_tuning[0] == 13 && D == 64)   // slot path on register staging instead of LDS-DMA (A/B)
+        rc = dkdv_launch<T, D, 32, 8, 128, 13>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 93)   // slot-interleaved path with phase stamps (never timed)
         rc = dkdv_launch<T, D, 32, 8, 128, 93>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 9)   // phased path with phase stamps (never timed)

@@ -735,7 +735,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   // Stage copies of Q and dO.  bf16, d >= 64: LDS-DMA, 1 KiB pieces (half an 8-row group at d = 128), the image's chunk swizzle
   // applied to each lane's source address; wave w moves pieces w, w + NW, ... (same swizzle parity, one lane offset) -- no
   // staging registers, no ds_write pass.  Otherwise (fp32's padded image, d = 32): registers, written after the MFMA phase.
-  constexpr bool DMA = sizeof(T) == 2 && D >= 64 && MODE != 9;
+  constexpr bool DMA = sizeof(T) == 2 && D >= 64 && MODE != 9 && MODE != 13;   // MODE 13: slot path on register staging (A/B)
   constexpr int PPG = D >= 128 ? 2 : 1;                          // pieces per 8-row group
   constexpr int NP = QS * D * (int)sizeof(T) / 1024, NPW = DMA ? NP / NW : 0;
   static_assert(!DMA || (NP % NW == 0 && NW % 4 == 0), "every wave moves whole pieces of one swizzle parity");
@@ -814,7 +814,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     //   slots 0-7   S', dP' of sub-slice i+1 (row constants enter as accumulator inputs)   | exp of sub-slice i
     //   slots 8-15  dV^T += dO^T P, dK^T += Q^T dS of sub-slice i                           | mul / pack of sub-slice i
     // LDS fragments are requested four slots before the MFMA that consumes them.
-    constexpr bool SLOT = !HD && (MODE == 3 || MODE == 93) && NSUB == 4 && D == 64 && KT == 1 && sizeof(T) == 2;
+    constexpr bool SLOT = !HD && (MODE == 3 || MODE == 93 || MODE == 13) && NSUB == 4 && D == 64 && KT == 1 && sizeof(T) == 2;
     if constexpr (SLOT) {
       const bool fast3 = (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
       if (fast3) {
