@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Forward only: slot-interleaved kernel vs the phased one (tuning key 1) at d = 128 and d = 64 shapes, with the max-abs
+difference of their outputs.  usage: python tools/bench_fwd_d128.py"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flash_attention_minitorch_amd import device_ops, _lib
 core = _lib.core()
