@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads of the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--phased", action="store_true",
+                    help="profiling A/B only: run the phased (round-1 v5) kernels instead of the MFMA-slot ones")
     return ap.parse_args()
 
 
@@ -70,6 +72,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from flash_attention_minitorch_amd import device_ops
+    if args.phased:
+        from flash_attention_minitorch_amd import _lib
+        for key, val in ((0, 4), (1, 2), (2, 2)):
+            _lib.core().fa_mi355x_set_tuning(key, val)
 
     B, H, N, d = args.batch, args.heads, args.seqlen, args.headdim
     BH = B * H
@@ -92,7 +98,7 @@ def main():
     # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
     # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
     # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
-    bf = args.dtype == "bf16" and not causal
+    bf = args.dtype == "bf16" and not causal and not args.phased
     K_FWD = "fwd_slot_kernel" if bf and ((d == 64) or (d == 128 and N % 64 == 0)) else "fwd_kernel"
     K_DQ = "bwd_dq_slot_kernel" if bf and d == 64 else "bwd_dq_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
