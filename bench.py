@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads of the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--no-sustained-peak", action="store_true")
     ap.add_argument("--phased", action="store_true",
                     help="profiling A/B only: run the phased (round-1 v5) kernels instead of the MFMA-slot ones")
     return ap.parse_args()
@@ -166,6 +167,19 @@ def main():
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(dur_ms, 4), "flops_per_launch": fl}
 
+    # what this device sustains on a bare bf16 MFMA loop with random operands (power-limited clock), measured live
+    sustained = None
+    if rank == 0 and args.dtype == "bf16" and not args.no_sustained_peak:
+        import ctypes
+        from flash_attention_minitorch_amd import _lib
+        tf, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _lib.check(_lib.core().fa_mi355x_measure_mfma_peak(300.0, ctypes.byref(tf), ctypes.byref(ghz),
+                                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        sustained = {"value": round(tf.value, 1), "unit": "TFLOP/s", "clock_GHz": round(ghz.value, 3),
+                     "what": "bare v_mfma_f32_32x32x16_bf16 loop, random operands, two waves per SIMD on every CU, >= 0.3 s"}
+        if roofline is not None and tf.value > 0:
+            roofline["frac_of_sustained_mfma"] = round(roofline["achieved"] / tf.value, 4)
+
     gather_ms = None
     if world > 1:
         from flash_attention_minitorch_amd import sharded
@@ -227,6 +241,7 @@ def main():
                        "parallelism": f"batch*head shard x{world}" if world > 1 else "single GPU"},
             "pct_mfma_roofline": round(100.0 * value / world / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 2),
             "roofline": roofline,
+            "sustained_mfma_peak": sustained,
             "cpu_baseline": cpu_baseline,
             "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),

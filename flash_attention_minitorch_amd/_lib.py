@@ -101,6 +101,8 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_version.restype = ctypes.c_char_p
     h.fa_mi355x_set_tuning.argtypes = [_i, _i]
     h.fa_mi355x_set_tuning.restype = _i
+    h.fa_mi355x_measure_mfma_peak.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]
+    h.fa_mi355x_measure_mfma_peak.restype = _i
     h.fa_mi355x_probe.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
     h.fa_mi355x_probe.restype = _i
     h._fa_typed = True

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <mutex>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -329,6 +330,49 @@ int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n) {
   if (!host_out || n <= 0 || n > 8 * 8192) return set_err(FA_ERR_BAD_ARG, "bad debug buffer");
   FA_HIP_TRY(hipDeviceSynchronize());
   FA_HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fa::g_phase_cycles), (size_t)n * sizeof(unsigned long long)));
+  return FA_OK;
+}
+
+int fa_mi355x_measure_mfma_peak(double min_ms, double* tflops, double* clock_ghz, void* stream) {
+  g_err[0] = 0;
+  if (!tflops || !clock_ghz || !(min_ms > 0)) return set_err(FA_ERR_BAD_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  FA_HIP_TRY(hipGetDevice(&dev));
+  FA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  const int blocks = prop.multiProcessorCount, iters = 4000;
+  float* sink = nullptr;
+  unsigned long long* stamps = nullptr;
+  FA_HIP_TRY(hipMalloc(&sink, (size_t)blocks * 512 * sizeof(float)));
+  FA_HIP_TRY(hipMalloc(&stamps, (size_t)blocks * 16 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  FA_HIP_TRY(hipEventCreate(&e0));
+  FA_HIP_TRY(hipEventCreate(&e1));
+  // back-to-back launches until min_ms have passed (the clock settles under load); the last batch is the one reported
+  double ms_per = 0.0, spent = 0.0;
+  int reps = 4;
+  for (int round = 0; round < 6 && spent < min_ms; ++round) {
+    FA_HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(fa::mfma_peak_kernel, dim3(blocks), dim3(512), 0, st, sink, stamps, iters);
+    FA_HIP_TRY(hipEventRecord(e1, st));
+    FA_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FA_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    ms_per = ms / reps;
+    spent += ms;
+    reps *= 2;
+  }
+  std::vector<unsigned long long> h((size_t)blocks * 16);
+  FA_HIP_TRY(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double cyc = 0, ticks = 0;
+  for (size_t i = 0; i + 1 < h.size(); i += 2) { cyc += (double)h[i]; ticks += (double)h[i + 1]; }
+  *clock_ghz = ticks > 0 ? cyc / ticks * 0.1 : 0.0;
+  *tflops = (double)blocks * 8.0 * iters * 8.0 * (2.0 * 32 * 32 * 16) / (ms_per * 1e-3) / 1e12;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(sink);
+  hipFree(stamps);
   return FA_OK;
 }
 

@@ -1633,6 +1633,40 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Measurement aid (bench.py "sustained_peak"): a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands in (-1, 1),
+// two waves per SIMD on every CU -- what the chip sustains under power on data like the attention operands (SURVEY.md
+// section 8d asks for this next to the nominal peak).  Writes per-wave cycles and 100 MHz ticks for the in-kernel clock.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) mfma_peak_kernel(float* __restrict__ sink, unsigned long long* __restrict__ stamps,
+                                                        int iters) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t st = 0x9E3779B9u * (uint32_t)(blockIdx.x * 512 + tid + 1);
+  auto rnd = [&]() {   // xorshift32 -> uniform in (-1, 1)
+    st ^= st << 13; st ^= st >> 17; st ^= st << 5;
+    return (float)(int32_t)st * (1.0f / 2147483648.0f);
+  };
+  bf16x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) { a[i][j] = (bf16_t)rnd(); b[i][j] = (bf16_t)rnd(); }
+  f32x16 c[4];
+  for (int i = 0; i < 4; ++i) c[i] = zero16();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 3], b[(u + (u >> 2)) & 3], c[u & 3], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 16; ++j) s += c[i][j];
+  sink[blockIdx.x * 512 + tid] = s;
+  if (lane == 0) {
+    stamps[(blockIdx.x * 8 + (tid >> 6)) * 2] = t1 - t0;
+    stamps[(blockIdx.x * 8 + (tid >> 6)) * 2 + 1] = r1 - r0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Layout probes (tests only): dump what the atoms read so the lane maps are checked against exact data.
 // 256 threads stage the tile (as the real kernels do); wave 0 runs the probes.
 // ---------------------------------------------------------------------------------------------

@@ -161,6 +161,11 @@ int fa_mi355x_set_tuning(int key, int value);
  * copies the first n counters (8 per wave slot) to host memory. */
 int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n);
 
+/* Measurement aid: runs a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands on every CU (two waves per SIMD) for
+ * at least min_ms and reports what the device SUSTAINS under power: dense bf16 TFLOP/s and the in-kernel clock (GHz).  bench.py
+ * prints it next to the nominal 2.5 PFLOP/s.  Synchronous. */
+int fa_mi355x_measure_mfma_peak(double min_ms, double* tflops, double* clock_ghz, void* stream);
+
 /* Test hook: dumps what the MFMA operand readers see for a [64][d] tile (tests/test_gpu_layout.py).
  * All pointers are device pointers; returns a status code. */
 int fa_mi355x_probe(const void* tile, const void* b, float* row_out, float* tr_out, float* mma_out,
