@@ -166,7 +166,18 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 8, 128, 93>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 9)   // phased path with phase stamps (never timed)
         rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else   // d = 64 default: slot-interleaved fast path for unmasked stages, per-sub-slice path on the causal diagonal
+      else if (D == 64 && !causal && (g_tuning[0] == 0 || g_tuning[0] == 193) && !lay.drop_thr) {
+        // d = 64, non-causal default: the continuous slot pipeline (no drain at stage boundaries, three-slot LDS-DMA ring)
+        const int nkb = (N + 255) / 256;
+        if (g_tuning[0] == 193)
+          hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                             (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        else
+          hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                             (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        FA_HIP_TRY(hipGetLastError());
+        rc = FA_OK;
+      } else   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
         // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
         rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {

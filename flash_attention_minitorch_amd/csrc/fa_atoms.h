@@ -201,6 +201,15 @@ FA_DEV void dma16(raw_rsrc_t rs, uint32_t lds_dst, int voff, int soff) {
       : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff)
       : "memory");
 }
+// the same for one dword per lane (256 B per wave-instruction): row constants
+FA_DEV void dma4(raw_rsrc_t rs, uint32_t lds_dst, int voff, int soff) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+}
 FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Register-staged global -> LDS tile copy of ROWS x D elements by NT threads, split into an early issue (load)

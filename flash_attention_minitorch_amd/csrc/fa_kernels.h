@@ -1167,6 +1167,265 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward dK / dV, continuous slot pipeline (bf16, d = 64, NON-CAUSAL launches): the geometry and the 16-slot period of
+// bwd_dkdv_kernel's MODE 3 (8 waves x 32 keys, 128-query stages of four 32-query sub-slices), but the pipeline never drains
+// at a stage boundary: period c of a stage issues S', dP' of sub-slice c+1 (sub-slice 0 of the NEXT stage when c = 3) beside
+// the exp / mul / pack and the dV^T, dK^T products of sub-slice c.  Stages (Q, dO tiles and the two row-constant vectors)
+// arrive by LDS-DMA into a three-slot ring; the barrier that publishes stage s+1 sits between periods 1 and 2 of stage s
+// (sub-slice 0 of stage s+1 is first requested in period 2), and its DMA is issued at the top of stage s into the slot of
+// stage s-2, which every wave left before that barrier of stage s-1.  No compiler-tracked global load in the loop.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int DIAG = 0>
+__global__ void __launch_bounds__(512)
+bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
+                     const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
+                     float* __restrict__ dv, int N, int nkb, int BH, Layout lay, float tau) {
+  static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
+  using A = Atom<T>;
+  typedef typename A::frag frag;
+  constexpr int KC = 4, QS = 128, NW = 8, KPW = 32, BK = NW * KPW;
+  constexpr int TB = A::template tile_bytes<D>(QS);   // 16 KiB
+  constexpr int BUF = 2 * TB + 8 * QS;                // Q tile, dO tile, QS x (-L/tau), QS x (-delta)
+  constexpr int SUBB = (D / 32) * 512 * 4;            // bytes of one 32-row sub-slice inside a tile image
+  __shared__ __attribute__((aligned(16))) char smem_raw[3 * BUF];
+  lds_char* smem = (lds_char*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, kb;
+  map_block(blockIdx.x, BH, nkb, bh, kb);
+  const int kw0 = kb * BK + w * KPW;
+  const bool active = kw0 < N;   // wave-uniform: a wave whose keys all lie past N only moves data and joins the barriers
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
+  const raw_rsrc_t qraw = make_raw_rsrc(q + base, mat_bytes), doraw = make_raw_rsrc(dout + base, mat_bytes);
+  const raw_rsrc_t nlraw = make_raw_rsrc(nlc + (size_t)bh * N, (uint32_t)N * 4u);
+  const raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
+  const float c = tau * LOG2E;
+
+  frag kf[KC], vf[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int off = ((kw0 + r) * ld + 16 * kc + 8 * h) * (int)sizeof(T);   // rows >= N read as zero
+    kf[kc] = load_frag_buf<T>(krs, off);
+    vf[kc] = load_frag_buf<T>(vrs, off);
+  }
+  const int key = kw0 + r;
+  const float km = (lay.kmask != nullptr && key < N) ? lay.kmask[(size_t)(bh / lay.mask_heads) * N + key] * LOG2E : 0.f;
+  f32x16 acc_dk[2], acc_dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    acc_dk[dt] = zero16();
+    acc_dv[dt] = zero16();
+  }
+
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+  const int nst = (N + QS - 1) / QS;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
+  // LDS-DMA: wave w moves pieces w and w + 8 (1 KiB = one 8-row group) of the Q and of the dO tile, waves 0-3 the row constants
+  const int dma_row7 = (lane >> 2) & 7;
+  const int dma_voff = dma_row7 * ld * (int)sizeof(T) + 16 * (4 * (lane >> 5) + ((lane & 3) ^ ((2 * (w & 1) + (dma_row7 >> 2)) & 3)));
+  auto stage_dma = [&](int st, int dst) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int g = w + 8 * g2;
+      const int soff = (st * QS + 8 * g) * ld * (int)sizeof(T);
+      dma16(qraw, smem_addr + dst + 1024 * g, dma_voff, soff);
+      dma16(doraw, smem_addr + dst + TB + 1024 * g, dma_voff, soff);
+    }
+    if (w < 4) {   // rows past N read as zero: P = exp2(c * S') stays finite and meets dO = 0, Q = 0
+      const int half = w & 1;
+      dma4((w < 2) ? nlraw : ndraw, smem_addr + dst + 2 * TB + ((w < 2) ? 0 : 4 * QS) + 256 * half, 4 * lane,
+           (st * QS + 64 * half) * 4);
+    }
+  };
+  auto slot_of = [&](int st) { return (st % 3) * BUF; };
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
+  if constexpr (DIAG) {
+    k_t0 = stamp();
+    k_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  stage_dma(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
+
+  f32x16 sA, dpA, sB, dpB, cS, cD;
+  frag pf0, pf1, df0, df1, rq[4], rdo[4], tf[4];
+  auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+  // LDS readers: per-stage address registers (row / transposed, two swizzle phases each) + immediates
+  auto rowf = [&](int b0, int b1, int tile_off, int sub, int kc) -> frag {
+    return *FA_LDS(frag, smem + ((kc & 1) ? b1 : b0) + tile_off + SUBB * sub + 512 * (kc >> 1));
+  };
+  auto trf = [&](int b0, int b1, int tile_off, int sub, int s2, int dt) -> frag {
+    const int kk = tile_off + SUBB * sub + (D / 32) * 512 * (2 * s2) + 512 * dt;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b0 + kk));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b1 + kk + (D / 32) * 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto ld_c = [&](f32x16& x, int hb /* stage base + 16 * h */, int off, int sub) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 a = *FA_LDS(f32x4, smem + hb + 2 * TB + off + 128 * sub + 32 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[4 * g + j] = a[j];
+    }
+  };
+  auto me = [&](f32x16& x, int i) { x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], c, km)); };
+  // One period.  SN: sub-slice whose S', dP' are produced, rows at (nr0, nr1) [its dO rows 1..3 are requested here]; SC:
+  // sub-slice in the softmax / dV, dK stream, transposed reads at (ct0, ct1); SP: the sub-slice after SN, whose Q rows, row
+  // constants and first dO row are requested in slots 12-15 at (pr0, pr1, ph16).
+  auto period = [&](auto hn_c, auto hc_c, auto subn_c, auto subc_c, auto subp_c, int nr0, int nr1, int ct0, int ct1, int pr0,
+                    int pr1, int ph16, f32x16& ns, f32x16& ndp, f32x16& cs, f32x16& cdp) {
+    constexpr bool HN = decltype(hn_c)::value != 0, HC = decltype(hc_c)::value != 0;
+    constexpr int SN = decltype(subn_c)::value, SC = decltype(subc_c)::value, SP = decltype(subp_c)::value;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3: S' chain | exp of scores 0..7 | dO rows 1..3
+      if constexpr (HN) {
+        if (kq == 0) A::mma_c(ns, rq[0], kf[0], cS);
+        else A::mma(ns, rq[kq], kf[kq]);
+        SB();
+        if (kq < 3) rdo[kq + 1] = rowf(nr0, nr1, TB, SN, kq + 1);
+      }
+      if constexpr (HC) { me(cs, 2 * kq); me(cs, 2 * kq + 1); }
+      SB();
+    }
+    // slot 4
+    if constexpr (HN) { A::mma_c(ndp, rdo[0], vf[0], cD); SB(); }
+    if constexpr (HC) {
+      pf0 = A::pack(cs, 0);
+      cdp[0] = cs[0] * cdp[0];
+      tf[0] = trf(ct0, ct1, TB, SC, 0, 0);
+    }
+    SB();
+#pragma unroll
+    for (int kq = 1; kq < 4; ++kq) {   // slots 5-7
+      if constexpr (HN) { A::mma(ndp, rdo[kq], vf[kq]); SB(); }
+      if constexpr (HC) {
+        me(cs, 6 + 2 * kq); me(cs, 7 + 2 * kq);
+        tf[kq] = trf(ct0, ct1, TB, SC, kq >> 1, kq & 1);
+      }
+      SB();
+    }
+    if constexpr (HC) {
+      A::mma(acc_dv[0], tf[0], pf0);   // slot 8
+      SB();
+      me(cs, 14); me(cs, 15);
+      tf[0] = trf(ct0, ct1, 0, SC, 0, 0);
+      SB();
+      A::mma(acc_dv[1], tf[1], pf0);   // slot 9
+      SB();
+      pf1 = A::pack(cs, 1);
+      cdp[1] = cs[1] * cdp[1];
+      tf[1] = trf(ct0, ct1, 0, SC, 0, 1);
+      SB();
+      A::mma(acc_dv[0], tf[2], pf1);   // slot 10
+      SB();
+#pragma unroll
+      for (int i = 2; i < 8; ++i) cdp[i] = cs[i] * cdp[i];
+      tf[2] = trf(ct0, ct1, 0, SC, 1, 0);
+      SB();
+      A::mma(acc_dv[1], tf[3], pf1);   // slot 11
+      SB();
+      df0 = A::pack(cdp, 0);
+      cdp[8] = cs[8] * cdp[8];
+      tf[3] = trf(ct0, ct1, 0, SC, 1, 1);
+      SB();
+      A::mma(acc_dk[0], tf[0], df0);   // slot 12
+      SB();
+#pragma unroll
+      for (int i = 9; i < 15; ++i) cdp[i] = cs[i] * cdp[i];
+    }
+    if constexpr (HN) {
+      rq[0] = rowf(pr0, pr1, 0, SP, 0);
+      rq[1] = rowf(pr0, pr1, 0, SP, 1);
+    }
+    SB();
+    if constexpr (HC) {   // slot 13
+      A::mma(acc_dk[1], tf[1], df0);
+      SB();
+      cdp[15] = cs[15] * cdp[15];
+      df1 = A::pack(cdp, 1);
+    }
+    if constexpr (HN) {
+      rq[2] = rowf(pr0, pr1, 0, SP, 2);
+      rq[3] = rowf(pr0, pr1, 0, SP, 3);
+    }
+    SB();
+    if constexpr (HC) { A::mma(acc_dk[0], tf[2], df1); SB(); }   // slot 14
+    if constexpr (HN) ld_c(cS, ph16, 0, SP);
+    SB();
+    if constexpr (HC) { A::mma(acc_dk[1], tf[3], df1); SB(); }   // slot 15
+    if constexpr (HN) {
+      ld_c(cD, ph16, 4 * QS, SP);
+      rdo[0] = rowf(pr0, pr1, TB, SP, 0);
+    }
+    SB();
+  };
+  auto T1 = ic<1>{};
+  auto T0 = ic<0>{};
+  int cr0 = ra.b[0], cr1 = ra.b[1], ct0 = ta.b[0], ct1 = ta.b[1], ch16 = 16 * h;   // addresses of the current stage (slot 0)
+  if (active) {
+    // operands of sub-slice 0, then its S', dP' alone (the pipeline fills)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) rq[kc] = rowf(cr0, cr1, 0, 0, kc);
+    ld_c(cS, ch16, 0, 0);
+    ld_c(cD, ch16, 4 * QS, 0);
+    rdo[0] = rowf(cr0, cr1, TB, 0, 0);
+    SB();
+    period(T1, T0, ic<0>{}, ic<0>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sA, dpA, sB, dpB);
+  }
+  for (int st = 0; st < nst; ++st) {
+    const int nb = slot_of(st + 1);
+    const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb, nh16 = 16 * h + nb;
+    if (st + 1 < nst) stage_dma(st + 1, nb);
+    if (active) {
+      period(T1, T1, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sB, dpB, sA, dpA);
+      period(T1, T1, ic<2>{}, ic<1>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sA, dpA, sB, dpB);
+    }
+    if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
+    dma_wait_all();   // this wave's pieces of the next stage have landed
+    if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
+    __syncthreads();
+    if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+    if (active) {
+      // sub-slice 0 of the next stage is requested from here on (after the last stage: stale data, results unused)
+      period(T1, T1, ic<3>{}, ic<2>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, nh16, sB, dpB, sA, dpA);
+      period(T1, T1, ic<0>{}, ic<3>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, nh16, sA, dpA, sB, dpB);
+    }
+    cr0 = nr0; cr1 = nr1; ch16 = nh16;
+    ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
+  }
+  if constexpr (DIAG) {
+    const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
+    ph[1] += k_t1 - t0;
+    const int slot = blockIdx.x * 8 + w;
+    if (slot < 8192 && lane == 0) {
+      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
+      g_phase_cycles[slot * 8 + 6] = k_t1 - k_t0;
+      g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
+    }
+  }
+  if (key < N) {
+    float* dkrow = dk + base + (size_t)key * ld;
+    float* dvrow = dv + base + (size_t)key * ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a = {acc_dk[dt][4 * g] * tau, acc_dk[dt][4 * g + 1] * tau, acc_dk[dt][4 * g + 2] * tau, acc_dk[dt][4 * g + 3] * tau};
+        f32x4 b = {acc_dv[dt][4 * g], acc_dv[dt][4 * g + 1], acc_dv[dt][4 * g + 2], acc_dv[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h) = a;
+        *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h) = b;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward dQ: same shape as the forward (4 waves x 32 query rows, K/V tiles of BN keys through LDS).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D, int BN, int FEAT = 0>

@@ -149,8 +149,9 @@ const char* fa_mi355x_last_error(void);
 const char* fa_mi355x_version(void);
 
 /* Tuning hook (in-process A/B benchmarks and tests only; every setting computes the same function).
- * key 0: dK/dV kernel, bf16 d <= 64 (0 default: slot-interleaved fast path at d = 64; 4 compiler-interleaved software
- *        pipeline; 1 plain; 2 four waves x 64 keys; 9 / 93 diagnostic builds with phase stamps, never timed)
+ * key 0: dK/dV kernel, bf16 d <= 64 (0 default: at d = 64 the continuous slot pipeline when non-causal, MODE 3 = slot fast
+ *        path + per-sub-slice path under the causal mask; 3 always MODE 3; 13 MODE 3 on register staging; 4 compiler-interleaved
+ *        software pipeline; 1 plain; 2 four waves x 64 keys; 9 / 93 / 193 diagnostic builds with phase stamps, never timed)
  * key 1: forward, bf16 d = 64, FA-2 side output (0 default: slot-interleaved kernel, phased under the causal mask;
  *        2 always phased; 3 always slot)
  * key 2: dQ, bf16 (0 default: slot-interleaved kernel at d = 64 non-causal, else 32-key tiles; 1 = 64-key tiles; 2 = 32-key

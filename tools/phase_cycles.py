@@ -15,7 +15,7 @@ core = _lib.core()
 core.fa_mi355x_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
 MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 KEY = 2 if MODE == 293 else (1 if MODE == 193 else 0)   # 293 / 193: the slot-interleaved dQ / forward kernel's stamps
-core.fa_mi355x_set_tuning(KEY, 93 if MODE in (293, 193) else MODE)
+core.fa_mi355x_set_tuning(KEY, 93 if MODE in (293, 193) else (193 if MODE == 393 else MODE))   # 393: continuous dK/dV kernel
 for _ in range(3):
     if KEY == 1:
         device_ops.flash_attn_fwd(q, k, v)
@@ -35,6 +35,8 @@ print("in-kernel clock GHz (median over waves):", round(float(np.median(life[ok]
 if MODE == 193:
     names = ["prologue (Q load, first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier",
              "epilogue (normalise, store O and L)", "-"]
+elif MODE == 393:
+    names = ["prologue (K/V fragments, first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier", "-", "-"]
 elif MODE == 293:
     names = ["prologue (first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier", "-", "-"]
 elif MODE == 93:
