@@ -102,8 +102,9 @@ def main():
     bf = args.dtype == "bf16" and not causal and not args.phased
     K_FWD = "fwd_slot_kernel" if bf and ((d == 64) or (d == 128 and N % 64 == 0)) else "fwd_kernel"
     K_DQ = "bwd_dq_slot_kernel" if bf and d == 64 else "bwd_dq_kernel"
+    K_DKDV = "bwd_dkdv_slot_kernel" if bf and d == 64 else "bwd_dkdv_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
-              ("bwd_dkdv_kernel", lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
+              (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
     breakdown = not args.no_kernel_breakdown
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)] \
         if breakdown else None
@@ -146,7 +147,7 @@ def main():
     if breakdown:
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
-        alg = {K_FWD: flops_fw, "bwd_prep_kernel": 0.0, "bwd_dkdv_kernel": 8.0 * BH * N * N * d * cf,
+        alg = {K_FWD: flops_fw, "bwd_prep_kernel": 0.0, K_DKDV: 8.0 * BH * N * N * d * cf,
                K_DQ: 2.0 * BH * N * N * d * cf}
         for i, (name, _) in enumerate(STAGES):
             ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / args.steps
