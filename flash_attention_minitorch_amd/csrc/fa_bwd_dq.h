@@ -1,0 +1,475 @@
+// FlashAttention backward for MI355X (gfx950): the query-stationary dQ kernels.
+// Part of the kernel set described in fa_kernels.h (included from there, inside its include order).
+#pragma once
+#include "fa_common.h"
+
+namespace fa {
+
+// ---------------------------------------------------------------------------------------------
+// Backward dQ: same shape as the forward (4 waves x 32 query rows, K/V tiles of BN keys through LDS).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int BN, int FEAT = 0>
+__global__ void __launch_bounds__(256)
+bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
+              const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
+              int BH, Layout lay, int causal, float tau) {
+  using A = Atom<T>;
+  typedef typename A::frag frag;
+  constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
+  constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
+  constexpr int TB = A::template tile_bytes<D>(BN);
+  __shared__ __attribute__((aligned(16))) char smem_raw[4 * TB];
+  __shared__ __attribute__((aligned(16))) float smask[HM ? 2 * BN : 4];   // key mask / tau of the two tiles in flight
+  lds_char* smem = (lds_char*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, qb;
+  map_block(blockIdx.x, BH, nqb, bh, qb);
+  if (causal) qb = nqb - 1 - qb;
+  const int q0 = qb * 128 + w * 32, qrow = q0 + r;
+  const bool qvalid = qrow < N;
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;   // elements between consecutive rows
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
+  const float c = tau * LOG2E;
+
+  frag qf[KC], dof[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int off = (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T);
+    qf[kc] = load_frag_buf<T>(qrs, off);
+    dof[kc] = load_frag_buf<T>(dors, off);
+  }
+  // this lane's row constants; -delta, in every register, is the accumulator input of the dP^T tiles
+  const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
+  const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  f32x16 nd16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nd16[i] = ndq;
+
+  f32x16 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = zero16();
+
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+  const int kmax = causal ? min(N, qb * 128 + 128) : N;
+  const int nt = (kmax + BN - 1) / BN;
+  TileStager<T, D, BN, 256> sk, sv;
+  sk.init(tid, ld);
+  sv.init(tid, ld);
+  sk.load(krs, 0);
+  sv.load(vrs, 0);
+  sk.store(smem);
+  sv.store(smem + 2 * TB);
+  const float* mrow = (HM && lay.kmask) ? lay.kmask + (size_t)(bh / lay.mask_heads) * N : nullptr;
+  const uint32_t dbase = HD ? drop_base(lay, bh, qrow) : 0u;
+  const float inv_tau = 1.0f / tau;
+  float mreg = 0.f;
+  auto mask_load = [&](int kb0) {
+    if constexpr (HM) {
+      if (tid < BN) mreg = (mrow != nullptr && kb0 + tid < N) ? mrow[kb0 + tid] * inv_tau : 0.f;
+    }
+  };
+  auto mask_store = [&](int par) {
+    if constexpr (HM) {
+      if (tid < BN) smask[par * BN + tid] = mreg;
+    }
+  };
+  mask_load(0);
+  mask_store(0);
+  __syncthreads();
+
+  auto tile = [&](auto par, int t) {
+    constexpr int PAR = decltype(par)::value;
+    const int kbase = t * BN;
+    const bool more = t + 1 < nt;
+    if (more) {
+      sk.load(krs, kbase + BN);
+      sv.load(vrs, kbase + BN);
+      mask_load(kbase + BN);
+    }
+    lds_char* tk = smem + PAR * TB;
+    lds_char* tv = smem + (2 + PAR) * TB;
+    const bool active = !causal || kbase <= q0 + 31;
+    if (active) {
+      f32x16 s[KT], dp[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        f32x16 mk16 = zero16();
+        if constexpr (HM) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(&smask[PAR * BN + 32 * kt + 8 * g + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mk16[4 * g + j] = mk[j];
+          }
+        }
+        A::mma_c(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, 0), qf[0], mk16);
+        if constexpr (HD) A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], zero16());
+        else A::mma_c(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, 0), dof[0], nd16);
+#pragma unroll
+        for (int kc = 1; kc < KC; ++kc) {
+          A::mma(s[kt], A::template row_frag<D>(tk, ra, 32 * kt, kc), qf[kc]);
+          A::mma(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, kc), dof[kc]);
+        }
+      }
+      const bool need_mask = causal && (kbase + BN - 1 > q0);
+      frag dsf[KT][2];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nlq));
+      if (need_mask) {   // diagonal tiles only (scalar branch)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kbase + 32 * kt + acc_row(i, h) > qrow) s[kt][i] = 0.f;
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if constexpr (HD) {
+            const bool keep = drop_keep(dbase, kbase + 32 * kt + acc_row(i, h), lay.drop_thr);
+            dp[kt][i] = s[kt][i] * ((keep ? dp[kt][i] * lay.drop_scale : 0.f) + ndq);
+          } else {
+            dp[kt][i] = s[kt][i] * dp[kt][i];
+          }
+        }
+        dsf[kt][0] = A::pack(dp[kt], 0);
+        dsf[kt][1] = A::pack(dp[kt], 1);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dsf[kt][s2]);
+    }
+    if (more) {
+      sk.store(smem + (PAR ^ 1) * TB);
+      sv.store(smem + (2 + (PAR ^ 1)) * TB);
+      mask_store(PAR ^ 1);
+    }
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile(ic<0>{}, t);
+    tile(ic<1>{}, t + 1);
+  }
+  if (t < nt) tile(ic<0>{}, t);
+
+  if (qvalid) {
+    float* row = dq + base + (size_t)qrow * ld;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 val = {acc[dt][4 * g] * tau, acc[dt][4 * g + 1] * tau, acc[dt][4 * g + 2] * tau,
+                     acc[dt][4 * g + 3] * tau};
+        *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * h) = val;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward dQ, slot-interleaved (bf16, d = 64): a workgroup = 8 waves = 256 query rows (two waves per SIMD), the query
+// on the lane as above.  Keys arrive in stages of 128 (K in a three-slot LDS ring, V in the matching slot 48 KiB
+// higher, so V reads share K's address registers) and are consumed as 32-key sub-tiles by a three-deep software
+// pipeline laid out in MFMA slots (see the dK/dV kernel): period j = 12 slots
+//   slots 0-3   S^T(j+1) = K Q^T          slots 4-7   dP^T(j+1) = V dO^T - delta      slots 8-11  dQ^T += K^T dS^T(j-1)
+// with the exp / mul / pack of sub-tile j spread over all twelve (24 issue cycles each) and every LDS fragment
+// requested four slots ahead.  The pipeline never drains at a stage boundary: the barrier that publishes stage s+1
+// sits in the middle of period 4s+2, and a stage's K slot is read (transposed, for dQ) two periods into the next
+// stage, hence the third ring slot.  Whole stages are always processed; sub-tiles beyond the causal diagonal or
+// N are masked (P = 0).
+// ---------------------------------------------------------------------------------------------
+// MASKS = false: non-causal launch with N a multiple of 128 (no sub-tile ever needs a mask): the masked period variants and
+// their register pressure at the joins disappear.
+template <typename T, int D, int DIAG = 0, bool MASKS = true>
+__global__ void __launch_bounds__(512)
+bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
+                   const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
+                   int BH, Layout lay, int causal, float tau) {
+  static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
+  using A = Atom<T>;
+  typedef typename A::frag frag;
+  constexpr int KC = D / 16, ST = 128, NT = 512;
+  constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB
+  constexpr int VOFF = 3 * TB;                        // V slot = K slot + 48 KiB
+  __shared__ __attribute__((aligned(16))) char smem_raw[6 * TB];
+  lds_char* smem = (lds_char*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, qb;
+  map_block(blockIdx.x, BH, nqb, bh, qb);
+  if (causal) qb = nqb - 1 - qb;
+  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
+  const bool qvalid = qrow < N;
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
+  const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
+  const float c = tau * LOG2E;
+
+  frag qf[KC], dof[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int off = (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T);
+    qf[kc] = load_frag_buf<T>(qrs, off);
+    dof[kc] = load_frag_buf<T>(dors, off);
+  }
+  const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
+  const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  f32x16 nd16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nd16[i] = ndq;
+  f32x16 acc[2];
+  acc[0] = zero16();
+  acc[1] = zero16();
+
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+  const int kmax = causal ? min(N, qb * 256 + 256) : N;
+  const int nstage = (kmax + ST - 1) / ST;
+  // Stage loads go global -> LDS directly (buffer_load ... lds, 1 KiB = 8 rows per wave-instruction, no staging
+  // registers): LDS-DMA writes lane-linearly, so the image's chunk swizzle is applied to each lane's SOURCE address.
+  // Wave w moves the 8-row groups w and w + 8 of K and of V (same parity, hence one lane offset).
+  const raw_rsrc_t kraw = make_raw_rsrc(k + base, mat_bytes), vraw = make_raw_rsrc(v + base, mat_bytes);
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
+  const int dma_row7 = (lane >> 2) & 7;
+  const int dma_voff = dma_row7 * ld * (int)sizeof(T) +
+                       16 * (4 * (lane >> 5) + ((lane & 3) ^ ((2 * (w & 1) + (dma_row7 >> 2)) & 3)));
+  auto stage_dma = [&](int row0, int slot_base) {
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int g = w + 8 * g2;
+      const int soff = (row0 + 8 * g) * ld * (int)sizeof(T);
+      dma16(kraw, smem_addr + slot_base + 1024 * g, dma_voff, soff);
+      dma16(vraw, smem_addr + slot_base + VOFF + 1024 * g, dma_voff, soff);
+    }
+  };
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
+  if constexpr (DIAG == 1) {
+    k_t0 = stamp();
+    k_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  if constexpr (MASKS) {   // see fwd_slot_kernel: stage rows past N must read as zeros
+#pragma unroll 4
+    for (int off = tid * 16; off < 6 * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
+  stage_dma(0, 0);
+  dma_wait_all();   // this wave's pieces have landed
+  __syncthreads();
+  if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
+
+  // sub-tile state: A / B alternate between "being produced" and "being consumed"
+  f32x16 sA, dpA, sB, dpB;
+  frag dsA0, dsA1, dsB0, dsB1;   // packed dS^T of the sub-tile before the current one / of the current one
+  frag rk[4], rv[4], tf[4];
+  auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+  // LDS readers on a per-stage address register + immediate
+  auto krow = [&](int b0, int b1, int sub, int kc) -> frag {
+    return *FA_LDS(frag, smem + ((kc & 1) ? b1 : b0) + (D / 32) * 512 * (4 * sub) + 512 * (kc >> 1));
+  };
+  auto ktr = [&](int b0, int b1, int sub, int s2, int dt) -> frag {
+    const int kk = (D / 32) * 512 * (4 * sub + 2 * s2) + 512 * dt;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b0 + kk));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(FA_LDS(bf16x4, smem + b1 + kk + (D / 32) * 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  // One period.  SUBN: sub-tile (0..3) whose S^T / dP^T are produced [row addresses rn*: its stage]; SUBP: the
+  // sub-tile whose dQ product is issued [transposed addresses tp*: its stage]; SUB2: the sub-tile two ahead, whose K
+  // rows are requested in slots 8-11 [row addresses r2*].  kcur: first key of the sub-tile in the exp / mul stream.
+  auto period = [&](auto hn_c, auto hc_c, auto hp_c, auto mask_c, auto subn_c, auto subp_c, auto sub2_c, int rn0, int rn1,
+                    int tp0, int tp1, int r20, int r21, int kcur, f32x16& ns, f32x16& ndp, f32x16& cs, f32x16& cdp,
+                    frag& dp0, frag& dp1, frag& dc0, frag& dc1) {
+    constexpr bool HN = decltype(hn_c)::value != 0, HC = decltype(hc_c)::value != 0, HP = decltype(hp_c)::value != 0;
+    constexpr bool MASK = decltype(mask_c)::value != 0;
+    constexpr int SUBN = decltype(subn_c)::value, SUBP = decltype(subp_c)::value, SUB2 = decltype(sub2_c)::value;
+    const int qlim = min(qrow, N - 1) - kcur;   // keep key offset o iff o <= qlim (non-causal: only the N bound)
+    const int klim = causal ? qlim : (N - 1 - kcur);
+    float cm = c;
+    if constexpr (MASK) asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the masked and unmasked variants' common fma
+    auto fe = [&](int i) {
+      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nlq));
+      if constexpr (MASK) pv = (acc_row(i, h) > klim) ? 0.f : pv;
+      cs[i] = pv;
+    };
+    auto md = [&](int i) { cdp[i] = cs[i] * cdp[i]; };
+    auto vrow = [&](int kq) -> frag {
+      return *FA_LDS(frag, smem + ((kq & 1) ? rn1 : rn0) + VOFF + (D / 32) * 512 * (4 * SUBN) + 512 * (kq >> 1));
+    };
+    // LDS fragments are requested LEAD slots before the MFMA that consumes them: 4 in the build without masked periods
+    // (186 VGPRs), 2 where the masked variants' joins leave no registers for more
+    constexpr int LEAD = MASKS ? 2 : 4;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 0-3: S^T of the next sub-tile
+      if constexpr (HN) {
+        if (kq == 0) A::mma_c(ns, rk[0], qf[0], zero16());
+        else A::mma(ns, rk[kq], qf[kq]);
+        SB();   // the MFMA opens its slot; the fillers follow in its shadow
+        if constexpr (LEAD == 4) rv[kq] = vrow(kq);
+        else if (kq >= 2) rv[kq - 2] = vrow(kq - 2);
+      }
+      if constexpr (HC) { fe(2 * kq); fe(2 * kq + 1); }
+      SB();
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 4-7: dP^T of the next sub-tile
+      if constexpr (HN) {
+        if (kq == 0) A::mma_c(ndp, rv[0], dof[0], nd16);
+        else A::mma(ndp, rv[kq], dof[kq]);
+        SB();
+        if constexpr (LEAD == 2) {
+          if (kq < 2) rv[kq + 2] = vrow(kq + 2);
+        }
+      }
+      if constexpr (HC) {
+        if (kq == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) md(i);
+        } else if (kq == 1) {
+          md(6); md(7); dc0 = A::pack(cdp, 0);
+        } else {
+          fe(4 + 2 * kq); fe(5 + 2 * kq);
+        }
+      }
+      if constexpr (HP) {
+        if constexpr (LEAD == 4) tf[kq] = ktr(tp0, tp1, SUBP, kq >> 1, kq & 1);
+        else if (kq >= 2) tf[kq - 2] = ktr(tp0, tp1, SUBP, 0, kq & 1);
+      }
+      SB();
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {   // slots 8-11: dQ^T of the previous sub-tile
+      if constexpr (HP) {
+        A::mma(acc[kq & 1], tf[kq], (kq < 2) ? dp0 : dp1);
+        SB();
+        if constexpr (LEAD == 2) {
+          if (kq < 2) tf[2 + kq] = ktr(tp0, tp1, SUBP, 1, kq);
+        }
+      }
+      if constexpr (HC) {
+        if (kq < 2) {
+          fe(12 + 2 * kq); fe(13 + 2 * kq);
+        } else if (kq == 2) {
+#pragma unroll
+          for (int i = 8; i < 14; ++i) md(i);
+        } else {
+          md(14); md(15); dc1 = A::pack(cdp, 1);
+        }
+      }
+      if constexpr (HN) {
+        if constexpr (LEAD == 4) {
+          rk[kq] = krow(r20, r21, SUB2, kq);
+        } else if (kq >= 2) {
+          rk[2 * (kq - 2)] = krow(r20, r21, SUB2, 2 * (kq - 2));
+          rk[2 * (kq - 2) + 1] = krow(r20, r21, SUB2, 2 * (kq - 2) + 1);
+        }
+      }
+      SB();
+    }
+  };
+  auto T1 = ic<1>{};
+  auto T0 = ic<0>{};
+  // per-stage address registers: K slot of stage s is s % 3
+  auto slot_of = [&](int st) { return (st % 3) * TB; };
+  int cr0 = ra.b[0], cr1 = ra.b[1];                 // rows of the current stage (slot 0)
+  int ct0 = ta.b[0], ct1 = ta.b[1];                 // transposed reads of the current stage
+  int pt0 = ct0, pt1 = ct1;                         // ... of the previous stage (stage 0: any finite data, dS = 0)
+  // prologue: rows of sub-tile 0, then S^T(0), dP^T(0)
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) rk[kc] = krow(cr0, cr1, 0, kc);
+  dsB0 = A::zero();
+  dsB1 = A::zero();
+  SB();
+  period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, 0, sA, dpA, sB, dpB, dsB0, dsB1, dsA0, dsA1);
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    const int nb = slot_of(st + 1);
+    const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;   // rows of the next stage
+    if (more) stage_dma((st + 1) * ST, nb);
+    const int kb = st * ST;
+    // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
+    auto need = [&](int sub) { return MASKS && ((kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0)); };
+    // period 4st+0: produce sub 1 (this stage), consume sub 0, dQ of sub 3 of the previous stage
+    if constexpr (MASKS) {
+      if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+      else period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    } else {
+      period(T1, T1, T1, T0, ic<1>{}, ic<3>{}, ic<2>{}, cr0, cr1, pt0, pt1, cr0, cr1, kb, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    }
+    // period 4st+1: produce sub 2, consume sub 1, dQ of sub 0
+    if constexpr (MASKS) {
+      if (need(1)) period(T1, T1, T1, T1, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+      else period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    } else {
+      period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, kb + 32, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    }
+    // the next stage goes to LDS and is published before the second half of period 4st+2 asks for its rows
+    if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; }
+    dma_wait_all();   // this wave's pieces of the next stage have landed
+    if constexpr (DIAG == 1) { t0 = stamp(); ph[2] += t0 - t1; }
+    if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
+    if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+    // period 4st+2: produce sub 3, consume sub 2, dQ of sub 1; rows two ahead = sub 0 of the next stage
+    if constexpr (MASKS) {
+      if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+      else period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    } else {
+      period(T1, T1, T1, T0, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+    }
+    // period 4st+3: produce sub 0 of the next stage, consume sub 3, dQ of sub 2
+    if constexpr (MASKS) {
+      if (need(3)) period(T1, T1, T1, T1, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+      else period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    } else {
+      period(T1, T1, T1, T0, ic<0>{}, ic<2>{}, ic<1>{}, nr0, nr1, ct0, ct1, nr0, nr1, kb + 96, sA, dpA, sB, dpB, dsA0, dsA1, dsB0, dsB1);
+    }
+    pt0 = ct0; pt1 = ct1;
+    cr0 = nr0; cr1 = nr1;
+    ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
+  }
+  // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
+  period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+
+  if constexpr (DIAG == 1) {
+    const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
+    ph[1] += k_t1 - t0;
+    const int slot = blockIdx.x * 8 + w;
+    if (slot < 8192 && lane == 0) {
+      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
+      g_phase_cycles[slot * 8 + 6] = k_t1 - k_t0;
+      g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
+    }
+  }
+  if (qvalid) {
+    float* row = dq + base + (size_t)qrow * ld;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 val = {acc[dt][4 * g] * tau, acc[dt][4 * g + 1] * tau, acc[dt][4 * g + 2] * tau,
+                     acc[dt][4 * g + 3] * tau};
+        *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * h) = val;
+      }
+  }
+}
+
+
+}  // namespace fa

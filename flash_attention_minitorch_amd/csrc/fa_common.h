@@ -1,0 +1,44 @@
+// Constants and small helpers shared by the FlashAttention kernels (fa_fwd.h, fa_bwd_dkdv.h, fa_bwd_dq.h, fa_aux.h);
+// the overview of the kernel set is in fa_kernels.h.
+#pragma once
+#include <type_traits>
+
+#include "fa_atoms.h"
+
+namespace fa {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int AUX_FA1 = 1;  // l = sum exp(s - m), m = row max            (src/flash_attn_fw.cu:259-276)
+constexpr int AUX_FA2 = 2;  // l = logsumexp, m untouched                  (src/flash_attn2_fw.cu:279-294)
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+// Diagnostic builds only (MODE == 9 instantiation of the dK/dV kernel): per-wave cycle totals per loop phase,
+// written to a buffer of their own that no other code reads.  The real kernels execute no stamp.
+__device__ unsigned long long g_phase_cycles[8 * 8192];
+FA_DEV unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <typename T> FA_DEV typename Atom<T>::frag load_frag_buf(rsrc_t rs, int byte_off);
+template <> FA_DEV bf16x8 load_frag_buf<bf16_t>(rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+template <> FA_DEV f32x8 load_frag_buf<float>(rsrc_t rs, int byte_off) {
+  f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+  f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16, 0, 0));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+FA_DEV f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+}  // namespace fa
