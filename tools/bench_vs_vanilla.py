@@ -49,6 +49,20 @@ for (B, H, N, d) in [(8, 8, 1024, 64), (8, 8, 2048, 64), (8, 8, 4096, 64)]:
         r = {"vanilla_fw_ms": round(t_ms(vanilla_fw), 3), "flash_fw_ms": round(t_ms(flash_fw), 3),
              "vanilla_fwbw_ms": round(t_ms(vanilla_fwbw), 3), "flash_fwbw_ms": round(t_ms(flash_fwbw), 3),
              "max_abs_diff_fw": round(err, 5)}
+        # the reference's per-phase "breakup" of the vanilla forward (kernel_tests/test_flashattn_breakdown.py:44-66:
+        # qk / mask / softmax / dropout (a 0/1 matrix product) / pv), each phase timed on its own
+        s0 = torch.matmul(q, k.transpose(1, 2)).float() * (d ** -0.5)
+        msk = mask if mask is not None else torch.zeros((N, N), device="cuda")
+        drop = torch.ones((N, N), device="cuda")
+        p0 = torch.softmax(s0 + msk, dim=-1)
+        pb = p0.to(torch.bfloat16)
+        r["vanilla_breakup_ms"] = {
+            "qk": round(t_ms(lambda: torch.matmul(q, k.transpose(1, 2)).float() * (d ** -0.5)), 3),
+            "mask": round(t_ms(lambda: s0 + msk), 3),
+            "softmax": round(t_ms(lambda: torch.softmax(s0, dim=-1)), 3),
+            "dropout": round(t_ms(lambda: p0 * drop), 3),
+            "pv": round(t_ms(lambda: torch.matmul(pb, v)), 3)}
+        del s0, p0, pb, drop, msk
         r["speedup_fw"] = round(r["vanilla_fw_ms"] / r["flash_fw_ms"], 2)
         r["speedup_fwbw"] = round(r["vanilla_fwbw_ms"] / r["flash_fwbw_ms"], 2)
         res[f"B{B}H{H}N{N}d{d}{'_causal' if causal else ''}"] = r
