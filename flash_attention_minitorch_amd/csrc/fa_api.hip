@@ -252,8 +252,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 
 // tau uses the caller's d even when the rows are zero-padded to dp columns (zero columns of Q/K add
 // nothing to the scores; zero columns of V produce zero output columns that are dropped).
-fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1, 0u, 1.0f, 0u}; }
-fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u}; }
+fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1, 0u, 1.0f, 0u, g_tuning[3]}; }
+fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u, g_tuning[3]}; }
 
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
                  int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st) {

@@ -278,6 +278,7 @@ struct Layout {
   uint32_t drop_thr;     // a position is kept iff its 24-bit uniform r24 >= drop_thr  (drop_thr = floor(rate * 2^24))
   float drop_scale;      // kept probabilities are multiplied by this (1 = minitorch's nn.dropout, 1/(1-rate) = inverted)
   uint32_t drop_seed;
+  int young_prio;        // slot kernels: waves 4-7 of a workgroup run at s_setprio 1 (0 = off); scheduling only
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two

@@ -626,6 +626,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
+  if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
   f32x16 sA, dpA, sB, dpB, cS, cD;
   frag pf0, pf1, df0, df1, rq[4], rdo[4], tf[4];
   auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };

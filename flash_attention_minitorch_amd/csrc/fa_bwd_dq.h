@@ -277,6 +277,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   __syncthreads();
   if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
+  if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
   // sub-tile state: A / B alternate between "being produced" and "being consumed"
   f32x16 sA, dpA, sB, dpB;
   frag dsA0, dsA1, dsB0, dsB1;   // packed dS^T of the sub-tile before the current one / of the current one

@@ -335,6 +335,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
+  if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
   f32x16 sA, sB;
   u32x4 pA0, pA1, pB0, pB1;   // packed P^T (bf16 pairs): chunks s2 = 0, 1 of the two sub-tiles in flight
   frag rk[4], tf[4];          // rings: K rows of the S^T chain, transposed V of the P.V chain (requested two slots ahead)

@@ -155,7 +155,8 @@ const char* fa_mi355x_version(void);
  * key 1: forward, bf16 d = 64, FA-2 side output (0 default: slot-interleaved kernel, phased under the causal mask;
  *        2 always phased; 3 always slot)
  * key 2: dQ, bf16 (0 default: slot-interleaved kernel at d = 64 non-causal, else 32-key tiles; 1 = 64-key tiles; 2 = 32-key
- *        tiles, phased kernel; 3 always slot; 93 / 94 diagnostic builds, never timed).  Other keys are reserved. */
+ *        tiles, phased kernel; 3 always slot; 93 / 94 diagnostic builds, never timed)
+ * key 3: 1 = waves 4-7 of the slot kernels run at s_setprio 1 (measured null; default 0).  Other keys are reserved. */
 int fa_mi355x_set_tuning(int key, int value);
 
 /* Profiling hook: per-wave cycle totals per loop phase written by a DIAGNOSTIC build (tuning key 0 = 9 / 93, key 2 = 93);
