@@ -185,8 +185,10 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (g_tuning[0] == 2)
         rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else
+      else if (g_tuning[0] == 5 || lay.drop_thr)   // two 128-key workgroups per CU (4 waves each); the dropout build needs its registers
         rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      else   // d = 128 default: 8 waves x 32 keys, one 256-key workgroup per CU (half the Q / dO staging per MFMA): 3.64 vs 3.92 ms
+        rc = dkdv_launch<T, D, 32, 8, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (D == 64) {
       // fp32, d = 64 (configs[1], [2]): the allocation lands on 256 VGPRs + 2 AGPRs = one wave per SIMD; asking for two
       // (launch bound) keeps it under 256 (tuning key 0 = 1: the unconstrained build)
