@@ -212,8 +212,15 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     if constexpr (sizeof(T) == 2 && D == 128) {
       if (g_tuning[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else
+      else if (g_tuning[2] == 4 || causal || lay.kmask || lay.drop_thr)   // 4 waves x 32 queries, two workgroups per CU
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+      else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
+        const int nqb = (N + 255) / 256;
+        hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+        FA_HIP_TRY(hipGetLastError());
+        rc = FA_OK;
+      }
     } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
       if (g_tuning[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);

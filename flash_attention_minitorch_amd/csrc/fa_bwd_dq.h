@@ -6,10 +6,11 @@
 namespace fa {
 
 // ---------------------------------------------------------------------------------------------
-// Backward dQ: same shape as the forward (4 waves x 32 query rows, K/V tiles of BN keys through LDS).
+// Backward dQ: same shape as the forward (NWQ waves x 32 query rows, K/V tiles of BN keys through LDS).  NWQ = 4 by
+// default; the bf16 d = 128 launch uses 8 (one workgroup per CU sharing each staged tile between twice the waves).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int BN, int FEAT = 0>
-__global__ void __launch_bounds__(256)
+template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4>
+__global__ void __launch_bounds__(64 * NWQ)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
               int BH, Layout lay, int causal, float tau) {
@@ -27,7 +28,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   int bh, qb;
   map_block(blockIdx.x, BH, nqb, bh, qb);
   if (causal) qb = nqb - 1 - qb;
-  const int q0 = qb * 128 + w * 32, qrow = q0 + r;
+  const int q0 = qb * (32 * NWQ) + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
@@ -58,9 +59,9 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
-  const int kmax = causal ? min(N, qb * 128 + 128) : N;
+  const int kmax = causal ? min(N, qb * (32 * NWQ) + 32 * NWQ) : N;
   const int nt = (kmax + BN - 1) / BN;
-  TileStager<T, D, BN, 256> sk, sv;
+  TileStager<T, D, BN, 64 * NWQ> sk, sv;
   sk.init(tid, ld);
   sv.init(tid, ld);
   sk.load(krs, 0);
