@@ -194,7 +194,14 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       // (launch bound) keeps it under 256 (tuning key 0 = 1: the unconstrained build)
       if (g_tuning[0] == 1 || lay.drop_thr)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else {
+      else if (g_tuning[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves
+        const int nkb = (N + 255) / 256;
+        hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 8, 32, 0, false, 2>), dim3(batch * nkb), dim3(512), 0, st,
+                           (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
+                           causal, tau);
+        FA_HIP_TRY(hipGetLastError());
+        rc = FA_OK;
+      } else {
         const int nkb = (N + 127) / 128;
         hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 4, 32, 0, false, 2>), dim3(batch * nkb), dim3(256), 0, st,
                            (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,

@@ -13,8 +13,9 @@ for a in sys.argv[1:]:
     if a.startswith("--knobs="):
         knobs = {int(kv.split(":")[0]): [int(x) for x in kv.split(":")[1].split(",")] for kv in a[8:].split()}
 causal = "--causal" in sys.argv
+DT = torch.float32 if "--f32" in sys.argv else torch.bfloat16
 BH = B * H
-mk = lambda: ((torch.rand((BH, N, d), device="cuda") - 0.5) * 2).to(torch.bfloat16)
+mk = lambda: ((torch.rand((BH, N, d), device="cuda") - 0.5) * 2).to(DT)
 q, k, v, do = mk(), mk(), mk(), mk()
 o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal)
 ws = device_ops.bwd_workspace(q)
