@@ -40,14 +40,15 @@ template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                    fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
+  const int nblk = causal ? (nqb + 1) / 2 : nqb;   // causal: query blocks p and nqb-1-p share a workgroup
   if (lay.drop_thr)   // dropout on P (and the key mask, staged as zeros when absent)
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 2>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q,
+    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 2>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
   else if (lay.kmask)   // additive key mask: staged per tile, enters S^T as the accumulator input
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 1>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q,
+    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 1>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
                        (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
   else
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
@@ -108,14 +109,15 @@ template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
               float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nqb = (N + 127) / 128;
+  const int nblk = causal ? (nqb + 1) / 2 : nqb;   // causal: query blocks p and nqb-1-p share a workgroup
   if (lay.drop_thr)
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 2>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 2>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   else if (lay.kmask)
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 1>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 1>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   else
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nqb), dim3(256), 0, st, (const T*)q, (const T*)k,
+    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;

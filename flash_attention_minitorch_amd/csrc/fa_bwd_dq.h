@@ -25,9 +25,13 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh, qb;
-  map_block(blockIdx.x, BH, nqb, bh, qb);
-  if (causal) qb = nqb - 1 - qb;
+  // causal launches pair query block p with block nqb-1-p in one workgroup (see fwd_kernel): uniform work per workgroup
+  const int nblk = causal ? (nqb + 1) / 2 : nqb;
+  int bh, pblk;
+  map_block(blockIdx.x, BH, nblk, bh, pblk);
+  const int npass = (causal && pblk != nqb - 1 - pblk) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qb = causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk;
   const int q0 = qb * (32 * NWQ) + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
   const size_t base = head_base(lay, bh);
@@ -180,6 +184,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
         *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * h) = val;
       }
   }
+  }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,9 +33,14 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
-  int bh, qb;
-  map_block(blockIdx.x, BH, nqb, bh, qb);
-  if (causal) qb = nqb - 1 - qb;  // heaviest query blocks first
+  // Causal launches pair query block p with block nqb-1-p in one workgroup (heavy one first): every workgroup then sweeps the
+  // same number of key tiles and the grid has no long tail (the launcher sizes the grid with fwd_blocks()).
+  const int nblk = causal ? (nqb + 1) / 2 : nqb;
+  int bh, pblk;
+  map_block(blockIdx.x, BH, nblk, bh, pblk);
+  const int npass = (causal && pblk != nqb - 1 - pblk) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qb = causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk;
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
   const size_t base = head_base(lay, bh);
@@ -234,6 +239,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
       }
     }
   }
+  }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------
