@@ -261,21 +261,24 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 // ---------------------------------------------------------------------------------------------
 // MASKS = false: the caller guarantees a non-causal launch with N a multiple of the stage (no sub-tile ever needs a mask),
 // which removes the masked period variants and their register pressure at the joins (needed at d = 128).
-template <typename T, int D, bool MASKS = true, int DIAG = 0>
-__global__ void __launch_bounds__(512)
+// STK: keys per stage (default: 16 KiB of K and of V); MINW: waves per SIMD the register allocation must allow (STK = 64 at
+// d = 64 halves the rings to 64 KiB, two workgroups per CU = four waves per SIMD at <= 128 VGPRs).
+template <typename T, int D, bool MASKS = true, int DIAG = 0, int STK = 8192 / D, int MINW = 2>
+__global__ void __launch_bounds__(512, MINW)
 fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
                 float* __restrict__ aux_l, int N, int nqb, int BH, Layout lay, int causal, float tau) {
   static_assert((D == 64 || D == 128) && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64 / 128");
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr int KC = D / 16, DT = D / 32, NS = 2 * KC, EPS = 16 / NS;   // slots per period, scores per slot
-  constexpr int ST = 8192 / D;                        // keys per stage: 16 KiB of K and of V
+  constexpr int ST = STK;                             // keys per stage
   constexpr int NSUBT = ST / 32;                      // sub-tiles per stage: 4 (d = 64) or 2 (d = 128)
   constexpr int R = NSUBT == 2 ? 4 : 3;               // ring slots
-  constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB
+  constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB (8 KiB with 64-key stages at d = 64)
+  constexpr int PCS = TB / 8192;                      // 1 KiB DMA pieces per wave and tensor
   constexpr int VOFF = R * TB;
   constexpr int SUBB = (D / 32) * 512 * 4;            // bytes of one 32-key sub-tile inside a stage image
-  static_assert(TB == 16384 && 2 * DT == KC, "stage geometry");
+  static_assert((TB == 16384 || TB == 8192) && 2 * DT == KC && (NSUBT == 2 || NSUBT == 4), "stage geometry");
   __shared__ __attribute__((aligned(16))) char smem_raw[2 * R * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
@@ -316,7 +319,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
                        16 * (4 * (2 * dma_half + (lane >> 5)) + ((lane & 3) ^ ((2 * dma_gpar + (dma_row7 >> 2)) & 3)));
   auto stage_dma = [&](int row0, int slot_base) {
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
+    for (int g2 = 0; g2 < PCS; ++g2) {
       const int piece = w + 8 * g2, g = piece / PPG;
       const int soff = (row0 + 8 * g) * ld * (int)sizeof(T);
       dma16(kraw, smem_addr + slot_base + 1024 * piece, dma_voff, soff);

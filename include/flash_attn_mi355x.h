@@ -153,7 +153,7 @@ const char* fa_mi355x_version(void);
  *        path + per-sub-slice path under the causal mask; 3 always MODE 3; 13 MODE 3 on register staging; 4 compiler-interleaved
  *        software pipeline; 1 plain; 2 four waves x 64 keys; 9 / 93 / 193 diagnostic builds with phase stamps, never timed)
  * key 1: forward, bf16 d = 64, FA-2 side output (0 default: slot-interleaved kernel, phased under the causal mask;
- *        2 always phased; 3 always slot)
+ *        2 always phased; 3 always slot; 6 the 128-key-stage slot build at two waves per SIMD)
  * key 2: dQ, bf16 (0 default: slot-interleaved kernel at d = 64 non-causal, else 32-key tiles; 1 = 64-key tiles; 2 = 32-key
  *        tiles, phased kernel; 3 always slot; 93 / 94 diagnostic builds, never timed)
  * key 3: 1 = waves 4-7 of the slot kernels run at s_setprio 1 (measured null; default 0).  Other keys are reserved. */
