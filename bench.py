@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- attention fw+bw throughput of the HIP path on MI355X, one JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 30
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -37,8 +37,8 @@ PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)   # the clock needs some tens of ms of load to settle
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--seqlen", type=int, default=4096)
