@@ -81,10 +81,7 @@ def main():
             dist.init_process_group(backend)
 
     from flash_attention_minitorch_amd import device_ops
-    if args.phased:
-        from flash_attention_minitorch_amd import _lib
-        for key, val in ((0, 4), (1, 2), (2, 2)):
-            _lib.core().fa_mi355x_set_tuning(key, val)
+    OPTS = device_ops.OPTS_PHASED if args.phased else None   # per-call kernel options (no process-wide state)
 
     B, H, N, d = args.batch, args.heads, args.seqlen, args.headdim
     BH = B * H
@@ -99,10 +96,10 @@ def main():
     ws = device_ops.bwd_workspace(q)
 
     def fwd():
-        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L)
+        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L, opts=OPTS)
 
     def bwd(stages=device_ops.STAGE_ALL):
-        device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages)
+        device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages, opts=OPTS)
 
     # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
     # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).

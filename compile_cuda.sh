@@ -13,13 +13,21 @@ ARCH="${FA_ARCH:-gfx950}"
 mkdir -p "$OUT_DIR"
 
 CORE="$OUT_DIR/libflash_attn_mi355x.so"
-if [ ! -f "$CORE" ] || [ -n "$(find "$SRC" "$HERE/include" -newer "$CORE" \( -name '*.h' -o -name '*.hip' \) -print -quit)" ]; then
+DIAG="$OUT_DIR/libflash_attn_mi355x_diag.so"   # stamp / ablation builds + fa_mi355x_set_tuning: tools/ only (FA_SKIP_DIAG=1 skips it)
+FLAGS=(--offload-arch="$ARCH" -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize ${FA_EXTRA_FLAGS:-})
+stale() { [ ! -f "$1" ] || [ -n "$(find "$SRC" "$HERE/include" -newer "$1" \( -name '*.h' -o -name '*.hip' \) -print -quit)" ]; }
+pids=()
+if stale "$CORE"; then
   echo "[compile_cuda.sh] hipcc --offload-arch=$ARCH  fa_api.hip -> $CORE"
-  "$HIPCC" --offload-arch="$ARCH" -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize ${FA_EXTRA_FLAGS:-} \
-      "$SRC/fa_api.hip" -o "$CORE"
+  "$HIPCC" "${FLAGS[@]}" "$SRC/fa_api.hip" -o "$CORE" & pids+=($!)
 else
   echo "[compile_cuda.sh] $CORE is up to date"
 fi
+if [ -z "${FA_SKIP_DIAG:-}" ] && stale "$DIAG"; then
+  echo "[compile_cuda.sh] hipcc --offload-arch=$ARCH  -DFA_DIAG fa_api.hip -> $DIAG"
+  "$HIPCC" "${FLAGS[@]}" -DFA_DIAG "$SRC/fa_api.hip" -o "$DIAG" & pids+=($!)
+fi
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 
 shim() {  # name variant FW|BW
   "$HIPCC" -O2 -fPIC -shared -x c++ "$SRC/fa_shim.cpp" -DFA_SHIM_VARIANT="$2" -DFA_SHIM_"$3" \

@@ -18,7 +18,10 @@ KERNEL_DIR = os.environ.get(
     "FA_MI355X_KERNEL_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "cuda_kernels")
 )
 
-CORE_NAME = "libflash_attn_mi355x.so"
+# FA_MI355X_DIAG=1 (tools/ only) loads the diagnostic build instead: stamp / ablation kernels and fa_mi355x_set_tuning live there,
+# never in the product library the tests, the shims and bench.py use.
+DIAG = bool(os.environ.get("FA_MI355X_DIAG"))
+CORE_NAME = "libflash_attn_mi355x_diag.so" if DIAG else "libflash_attn_mi355x.so"
 VARIANT_LIBS = (
     "flash_attn_fw.so",
     "flash_attn_bw.so",
@@ -99,14 +102,32 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_last_error.restype = ctypes.c_char_p
     h.fa_mi355x_version.argtypes = []
     h.fa_mi355x_version.restype = ctypes.c_char_p
-    h.fa_mi355x_set_tuning.argtypes = [_i, _i]
-    h.fa_mi355x_set_tuning.restype = _i
+    _ip = ctypes.POINTER(ctypes.c_int)
+    h.fa_mi355x_fwd_ex.argtypes = [_vp] * 6 + [_i] * 6 + [_ip, _i, _vp]
+    h.fa_mi355x_fwd_ex.restype = _i
+    h.fa_mi355x_bwd_ex.argtypes = [_vp] * 11 + [_i] * 7 + [_ip, _i, _vp]
+    h.fa_mi355x_bwd_ex.restype = _i
+    h.fa_mi355x_bwd_status.argtypes = [_vp, _i, _i, _i, _ip]
+    h.fa_mi355x_bwd_status.restype = _i
+    if DIAG:
+        h.fa_mi355x_set_tuning.argtypes = [_i, _i]
+        h.fa_mi355x_set_tuning.restype = _i
+        h.fa_mi355x_debug_phase_cycles.argtypes = [_vp, _i]
+        h.fa_mi355x_debug_phase_cycles.restype = _i
     h.fa_mi355x_measure_mfma_peak.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]
     h.fa_mi355x_measure_mfma_peak.restype = _i
     h.fa_mi355x_probe.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
     h.fa_mi355x_probe.restype = _i
     h._fa_typed = True
     return h
+
+
+def opts_array(opts):
+    """ctypes (pointer, count) of a per-call option list for the *_ex entry points (None: defaults)."""
+    if not opts:
+        return None, 0
+    arr = (ctypes.c_int * len(opts))(*[int(x) for x in opts])
+    return arr, len(opts)
 
 
 def check(status: int) -> None:

@@ -4,6 +4,7 @@
 // src/flash_attn_bw.cu:275-365, src/flash_attn2_fw.cu:310-372, src/flash_attn2_bw.cu:277-369).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 #include <stdio.h>
@@ -34,7 +35,59 @@ int set_err(int code, const char* what, hipError_t e = hipSuccess) {
 inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
 inline int d_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
 
-int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fa_mi355x_set_tuning(): [0] dK/dV geometry, [1] fwd, [2] dQ tile
+// Per-call kernel selection (fa_mi355x_fwd_ex / fa_mi355x_bwd_ex; every other entry point runs the defaults): [0] dK/dV geometry,
+// [1] forward kernel, [2] dQ kernel, [3] 1 = s_setprio 1 for waves 4-7 of the slot kernels, [4] 2 = one-pass backward, [5] (FA_DIAG
+// builds only) timing ablations of the one-pass backward.  The product library accepts only values whose kernels give correct
+// results; stamp builds, A/B staging variants and ablations exist in the FA_DIAG build alone (libflash_attn_mi355x_diag.so, tools/).
+struct Tun { int v[8]; };
+#ifdef FA_DIAG
+int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // fa_mi355x_set_tuning(): process-wide defaults of the diagnostic build
+#endif
+inline Tun default_tun() {
+  Tun t = {{0, 0, 0, 0, 0, 0, 0, 0}};
+#ifdef FA_DIAG
+  for (int i = 0; i < 8; ++i) t.v[i] = g_tuning[i];
+#endif
+  return t;
+}
+int parse_opts(const int* opts, int nopts, Tun& t) {
+  t = default_tun();
+  if (nopts < 0 || nopts > 8 || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
+  for (int i = 0; i < nopts; ++i) t.v[i] = opts[i];
+#ifndef FA_DIAG
+  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, -1}, {0, -1}, {0, -1}};
+  for (int i = 0; i < 8; ++i) {
+    bool ok = false;
+    for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
+    if (!ok) return set_err(FA_ERR_BAD_ARG, "option value not available in the product library (diagnostic builds only)");
+  }
+#endif
+  return FA_OK;
+}
+
+// ---- workspace of the one-pass backward (bwd_fused_kernel) ---------------------------------------------------------
+// [ -L/tau : rows floats ][ -delta : rows floats ] (pad to 256 B) [ control: 256 B, word 0 = error ][ flags: FUSED_FLAG_BYTES ]
+// [ zero page 2 KiB | dummy page 2 KiB ][ running dQ tiles: ngroups * N * 64 floats ]
+constexpr size_t FUSED_CTL_BYTES = fa::FUSED_FLAG0, FUSED_FLAG_BYTES = fa::FUSED_FLAG_BYTES;
+constexpr int FUSED_MAX_CUS = 512;   // sizing bound only (flags: 4 * CUs words; slabs: CUs * 64 KiB)
+inline size_t align256z(size_t x) { return (x + 255) & ~(size_t)255; }
+inline bool fused_shape(int N, int d) { return d == 64 && N >= 256 && N % 256 == 0 && N / 256 <= FUSED_MAX_CUS; }
+inline size_t fused_extra_bytes(int batch, int N, int d) {
+  if (!fused_shape(N, d)) return 0;
+  const size_t groups = (size_t)std::min(batch, std::max(1, FUSED_MAX_CUS / (N / 256)));
+  return FUSED_CTL_BYTES + FUSED_FLAG_BYTES + fa::FUSED_PAGES + groups * (size_t)N * 64 * sizeof(float);
+}
+int device_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
 
 template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
@@ -56,21 +109,23 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
 
 template <typename T, int D>
 int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
-               fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
+               fa::Layout lay, int causal, int variant, float tau, hipStream_t st, const Tun& tun) {
   if constexpr (sizeof(T) == 2 && (D == 64 || D == 128)) {
     // FA-2 side output, bf16, d = 64 / 128, non-causal: slot-interleaved three-deep pipeline.  Under the causal mask the phased
     // kernel (128-query workgroups, per-wave tile skipping) measured 3.6 % faster, so it keeps that case; tuning key 1:
     // 2 = always phased, 3 = always slot.
-    if (variant == FA_VARIANT_FA2 && g_tuning[1] != 2 && (!causal || g_tuning[1] == 3) && !lay.kmask && !lay.drop_thr) {
+    if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3) && !lay.kmask && !lay.drop_thr) {
       const int nqb = (N + 255) / 256;
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
-      if (whole && g_tuning[1] == 93 && D == 64) {   // phase stamps (never timed)
+#ifdef FA_DIAG
+      if (whole && tun.v[1] == 93 && D == 64) {   // phase stamps (never timed)
         hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 1>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
-      if (whole && g_tuning[1] != 6 && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
+#endif
+      if (whole && tun.v[1] != 6 && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)
         hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
@@ -99,12 +154,16 @@ template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                 float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
-  if (lay.drop_thr) {   // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key)
-    hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
-                       (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
-                       causal, tau);
-    FA_HIP_TRY(hipGetLastError());
-    return FA_OK;
+  // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key).  (Not instantiated for the 8-wave d = 128
+  // geometry, which dropout calls never take: that build would need 268 registers.)
+  if constexpr (!(sizeof(T) == 2 && D == 128 && NW == 8)) {
+    if (lay.drop_thr) {
+      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
+                         (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
+                         causal, tau);
+      FA_HIP_TRY(hipGetLastError());
+      return FA_OK;
+    }
   }
   hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
                      (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau);
@@ -147,7 +206,7 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
 template <typename T, int D>
 int bwd_launch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
                float* dv, const float* l, const float* m, float* ws, int batch, int N, fa::Layout lay, int causal,
-               int variant, float tau, int stages, hipStream_t st) {
+               int variant, float tau, int stages, hipStream_t st, const Tun& tun) {
   const long rows = (long)batch * N;
   float* nlc = ws;
   float* delta = ws + rows;
@@ -157,53 +216,104 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
                        (const T*)dout, l, m, nlc, delta, rows, N, lay, variant, 1.0f / tau);
     FA_HIP_TRY(hipGetLastError());
   }
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    // One pass for dQ, dK, dV (five products instead of seven): non-causal, N a multiple of 256, all members of a head's
+    // hand-off chain resident (N / 256 workgroups of one per CU).  Opt-in (option 4 = 2): measured 3-8 % SLOWER than the two-kernel
+    // backward up to N = 8192 and 3 % faster at N = 16384 (profiles/README.md, round 2), so the default stays two kernels.
+    const int both = FA_BWD_STAGE_DKDV | FA_BWD_STAGE_DQ;
+    const int cus = device_cus();
+    if ((stages & both) == both && tun.v[4] == 2 && !causal && !lay.kmask &&
+        !lay.drop_thr && fused_shape(N, D) && N / 256 <= cus && cus <= FUSED_MAX_CUS) {
+      const int nkb = N / 256;
+      const int xcdmap = (cus == 256 && nkb <= 32 && 32 % nkb == 0) ? 1 : 0;
+      const int avail = xcdmap ? 8 * (32 / nkb) : cus / nkb;
+      const int ngroups = std::min(avail, batch);
+      const int grid = xcdmap ? 256 : ngroups * nkb;
+      char* fz = (char*)ws + align256z((size_t)2 * rows * sizeof(float));
+      unsigned* hand = (unsigned*)fz;
+      FA_HIP_TRY(hipMemsetAsync(fz, 0, FUSED_CTL_BYTES + FUSED_FLAG_BYTES + fa::FUSED_PAGES / 2, st));   // error word, flags, zero page: every call
+#define FA_FUSED_LAUNCH(ABL)                                                                                              \
+  hipLaunchKernelGGL((fa::bwd_fused_kernel<T, 64, ABL>), dim3(grid), dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, \
+                     (const T*)dout, nlc, delta, dq, dk, dv, hand, N, nkb, batch, ngroups, xcdmap, lay, tau)
+#ifdef FA_DIAG
+      switch (tun.v[5]) {   // timing ablations (wrong results) and phase stamps: see bwd_fused_kernel
+        case 1: FA_FUSED_LAUNCH(1); break;
+        case 2: FA_FUSED_LAUNCH(2); break;
+        case 3: FA_FUSED_LAUNCH(3); break;
+        case 7: FA_FUSED_LAUNCH(7); break;
+        case 8: FA_FUSED_LAUNCH(8); break;
+        case 32: FA_FUSED_LAUNCH(32); break;
+        case 33: FA_FUSED_LAUNCH(33); break;
+        case 64: FA_FUSED_LAUNCH(64); break;
+        case 128: FA_FUSED_LAUNCH(128); break;
+        case 256: FA_FUSED_LAUNCH(256); break;
+        case 192: FA_FUSED_LAUNCH(192); break;
+        case 320: FA_FUSED_LAUNCH(320); break;
+        case 384: FA_FUSED_LAUNCH(384); break;
+        default: FA_FUSED_LAUNCH(0); break;
+      }
+#else
+      FA_FUSED_LAUNCH(0);
+#endif
+#undef FA_FUSED_LAUNCH
+      FA_HIP_TRY(hipGetLastError());
+      return FA_OK;
+    }
+  }
   if (stages & FA_BWD_STAGE_DKDV) {
     int rc;
     if constexpr (sizeof(T) == 2 && D <= 64) {
       // measured at B=8,H=8,N=4096,d=64 (ms, one device, profiles/README.md): 8 waves x 32 keys, 128-query stages,
       // software-pipelined sub-slices 0.505; not pipelined 0.514; 64-query stages 0.519; 256-query 0.525;
       // 4 waves x 32 keys (two workgroups per CU) 0.521; 4 waves x 64 keys (one wave per SIMD) 0.559
-      if (g_tuning[0] == 1)
+      if (tun.v[0] == 1)
         rc = dkdv_launch<T, D, 32, 8, 128, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 2)
+      else if (tun.v[0] == 2)
         rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 4 || D != 64)   // compiler-interleaved software pipeline (the d = 32 default)
+      else if (tun.v[0] == 4 || D != 64)   // compiler-interleaved software pipeline (the d = 32 default)
         rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 13 && D == 64)   // slot path on register staging instead of LDS-DMA (A/B)
+#ifdef FA_DIAG
+      else if (tun.v[0] == 13 && D == 64)   // slot path on register staging instead of LDS-DMA (A/B)
         rc = dkdv_launch<T, D, 32, 8, 128, 13>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 93)   // slot-interleaved path with phase stamps (never timed)
+      else if (tun.v[0] == 93)   // slot-interleaved path with phase stamps (never timed)
         rc = dkdv_launch<T, D, 32, 8, 128, 93>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 9)   // phased path with phase stamps (never timed)
+      else if (tun.v[0] == 9)   // phased path with phase stamps (never timed)
         rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (D == 64 && !causal && (g_tuning[0] == 0 || g_tuning[0] == 193) && !lay.drop_thr) {
+      else if (D == 64 && !causal && tun.v[0] == 193 && !lay.drop_thr) {   // continuous slot pipeline with phase stamps
+        const int nkb = (N + 255) / 256;
+        hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        FA_HIP_TRY(hipGetLastError());
+        rc = FA_OK;
+      }
+#endif
+      else if (D == 64 && !causal && tun.v[0] == 0 && !lay.drop_thr) {
         // d = 64, non-causal default: the continuous slot pipeline (no drain at stage boundaries, three-slot LDS-DMA ring)
         const int nkb = (N + 255) / 256;
-        if (g_tuning[0] == 193)
-          hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
-                             (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
-        else
+        {
           hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                              (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        }
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
       } else   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
         // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
         rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {
-      if (g_tuning[0] == 1)
+      if (tun.v[0] == 1)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 2)
+      else if (tun.v[0] == 2)
         rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 5 || lay.drop_thr)   // two 128-key workgroups per CU (4 waves each); the dropout build needs its registers
+      else if (tun.v[0] == 5 || lay.drop_thr)   // two 128-key workgroups per CU (4 waves each); the dropout build needs its registers
         rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else   // d = 128 default: 8 waves x 32 keys, one 256-key workgroup per CU (half the Q / dO staging per MFMA): 3.64 vs 3.92 ms
         rc = dkdv_launch<T, D, 32, 8, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
     } else if constexpr (D == 64) {
       // fp32, d = 64 (configs[1], [2]): the allocation lands on 256 VGPRs + 2 AGPRs = one wave per SIMD; asking for two
       // (launch bound) keeps it under 256 (tuning key 0 = 1: the unconstrained build)
-      if (g_tuning[0] == 1 || lay.drop_thr)
+      if (tun.v[0] == 1 || lay.drop_thr)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (g_tuning[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves
+      else if (tun.v[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves
         const int nkb = (N + 255) / 256;
         hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 8, 32, 0, false, 2>), dim3(batch * nkb), dim3(512), 0, st,
                            (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
@@ -226,9 +336,9 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
   if (stages & FA_BWD_STAGE_DQ) {
     int rc;
     if constexpr (sizeof(T) == 2 && D == 128) {
-      if (g_tuning[2] == 1)
+      if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (g_tuning[2] == 4 || causal || lay.kmask || lay.drop_thr)   // 4 waves x 32 queries, two workgroups per CU
+      else if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr)   // 4 waves x 32 queries, two workgroups per CU
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
         const int nqb = (N + 255) / 256;
@@ -238,19 +348,21 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = FA_OK;
       }
     } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
-      if (g_tuning[2] == 1)
+      if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (g_tuning[2] == 2 || lay.kmask || lay.drop_thr || (causal && g_tuning[2] != 3))   // key mask and dropout live in the
+      else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || (causal && tun.v[2] != 3))   // key mask and dropout live in the
         // phased kernel, which is also 1 % faster under the causal mask (tuning key 2 = 3 forces the slot kernel)
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (g_tuning[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
+#ifdef FA_DIAG
+      else if (tun.v[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
         rc = dq_slot_launch<T, D, 2>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (g_tuning[2] == 93)   // phase stamps (never timed)
+      else if (tun.v[2] == 93)   // phase stamps (never timed)
         rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+#endif
       else
         rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
     } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
-      if (g_tuning[2] == 1)
+      if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
@@ -277,20 +389,22 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 
 // tau uses the caller's d even when the rows are zero-padded to dp columns (zero columns of Q/K add
 // nothing to the scores; zero columns of V produce zero output columns that are dropped).
-fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1, 0u, 1.0f, 0u, g_tuning[3]}; }
-fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u, g_tuning[3]}; }
+fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1, 0u, 1.0f, 0u, 0}; }
+fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u, 0}; }
 
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
-                 int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st) {
+                 int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st, const Tun& tun = default_tun()) {
   const float tau = sqrtf(1.0f / (float)d);
-  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st);
+  lay.young_prio = tun.v[3];
+  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st, tun);
 }
 
 int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
                  float* dv, const float* l, const float* m, float* ws, int batch, int N, int d, int dp, fa::Layout lay,
-                 int causal, int variant, int dtype, int stages, hipStream_t st) {
+                 int causal, int variant, int dtype, int stages, hipStream_t st, const Tun& tun = default_tun()) {
   const float tau = sqrtf(1.0f / (float)d);
-  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, lay, causal, variant, tau, stages, st);
+  lay.young_prio = tun.v[3];
+  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, lay, causal, variant, tau, stages, st, tun);
 }
 
 int check_common(int batch, int N, int d, int variant, int dtype) {
@@ -361,6 +475,7 @@ extern "C" {
 const char* fa_mi355x_last_error(void) { return g_err; }
 const char* fa_mi355x_version(void) { return "flash_attn_mi355x 0.2 gfx950"; }
 
+#ifdef FA_DIAG
 int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n) {
   g_err[0] = 0;
   if (!host_out || n <= 0 || n > 8 * 8192) return set_err(FA_ERR_BAD_ARG, "bad debug buffer");
@@ -368,6 +483,13 @@ int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n) {
   FA_HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fa::g_phase_cycles), (size_t)n * sizeof(unsigned long long)));
   return FA_OK;
 }
+
+int fa_mi355x_set_tuning(int key, int value) {
+  if (key < 0 || key >= 8) return set_err(FA_ERR_BAD_ARG, "unknown tuning key");
+  g_tuning[key] = value;
+  return FA_OK;
+}
+#endif
 
 int fa_mi355x_measure_mfma_peak(double min_ms, double* tflops, double* clock_ghz, void* stream) {
   g_err[0] = 0;
@@ -412,12 +534,6 @@ int fa_mi355x_measure_mfma_peak(double min_ms, double* tflops, double* clock_ghz
   return FA_OK;
 }
 
-int fa_mi355x_set_tuning(int key, int value) {
-  if (key < 0 || key >= 8) return set_err(FA_ERR_BAD_ARG, "unknown tuning key");
-  g_tuning[key] = value;
-  return FA_OK;
-}
-
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                   int d, int causal, int variant, int dtype, void* stream) {
   g_err[0] = 0;
@@ -427,6 +543,34 @@ int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
   return fwd_dispatch(q, k, v, out, l, m, batch, N, d, d, bhnd(N, d), causal ? 1 : 0, variant, dtype,
                       (hipStream_t)stream);
+}
+
+int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
+                     int causal, int variant, int dtype, const int* opts, int nopts, void* stream) {
+  g_err[0] = 0;
+  Tun tun;
+  if (int rc = parse_opts(opts, nopts, tun)) return rc;
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  return fwd_dispatch(q, k, v, out, l, m, batch, N, d, d, bhnd(N, d), causal ? 1 : 0, variant, dtype, (hipStream_t)stream, tun);
+}
+
+int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                     float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
+                     int causal, int variant, int dtype, int stages, const int* opts, int nopts, void* stream) {
+  g_err[0] = 0;
+  Tun tun;
+  if (int rc = parse_opts(opts, nopts, tun)) return rc;
+  if (stages <= 0 || stages > FA_BWD_STAGE_ALL) return set_err(FA_ERR_BAD_ARG, "bad stages mask");
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, batch, N, d, d, bhnd(N, d),
+                      causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream, tun);
 }
 
 int fa_mi355x_fwd_layout(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H,
@@ -547,9 +691,23 @@ int fa_mi355x_bwd_dropout(const void* q, const void* k, const void* v, const flo
 }
 
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d) {
-  (void)d;
   if (batch <= 0 || N <= 0) return 0;
-  return (size_t)2 * batch * N * sizeof(float);
+  const size_t rowc = (size_t)2 * batch * N * sizeof(float);
+  const size_t extra = fused_extra_bytes(batch, N, d);
+  return extra ? align256z(rowc) + extra : rowc;
+}
+
+int fa_mi355x_bwd_status(const void* workspace, int batch, int N, int d, int* status) {
+  g_err[0] = 0;
+  if (!workspace || !status || batch <= 0 || N <= 0) return set_err(FA_ERR_BAD_ARG, "bad argument");
+  *status = 0;
+  if (!fused_extra_bytes(batch, N, d)) return FA_OK;
+  unsigned word = 0;
+  FA_HIP_TRY(hipMemcpy(&word, (const char*)workspace + align256z((size_t)2 * batch * N * sizeof(float)), sizeof(word),
+                       hipMemcpyDeviceToHost));
+  *status = (int)word;
+  if (word) return set_err(FA_ERR_HIP, "one-pass backward: a hand-off wait timed out (a chain member was not running)");
+  return FA_OK;
 }
 
 int fa_mi355x_bwd(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,

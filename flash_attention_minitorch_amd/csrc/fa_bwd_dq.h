@@ -124,18 +124,22 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
           A::mma(dp[kt], A::template row_frag<D>(tv, ra, 32 * kt, kc), dof[kc]);
         }
       }
-      const bool need_mask = causal && (kbase + BN - 1 > q0);
+      // keys past N read K = 0, so S = 0 and P = exp2(-L * log2e): finite garbage for ordinary rows, but +inf for a row whose
+      // logsumexp lies below about -88 (then dS = inf * 0 = NaN poisons the row's dQ): the ragged tail is masked like the diagonal
+      const bool need_mask = (kbase + BN > N) || (causal && (kbase + BN - 1 > q0));
       frag dsf[KT][2];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], c, nlq));
-      if (need_mask) {   // diagonal tiles only (scalar branch)
+      if (need_mask) {   // diagonal tiles and the ragged last tile only (scalar branch)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (kbase + 32 * kt + acc_row(i, h) > qrow) s[kt][i] = 0.f;
+          for (int i = 0; i < 16; ++i) {
+            const int key = kbase + 32 * kt + acc_row(i, h);
+            if (key >= N || (causal && key > qrow)) s[kt][i] = 0.f;
+          }
       }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
@@ -240,9 +244,12 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   }
   const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
   const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  // -delta enters dP^T as the accumulator input of its MFMA chain (sixteen registers holding one value).  The build with masked
+  // periods has no registers for that (it spilled three around the loop): there the VALU adds it, dS = P * (dP + (-delta)).
+  constexpr bool NDACC = !MASKS;
   f32x16 nd16;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) nd16[i] = ndq;
+  for (int i = 0; i < 16; ++i) nd16[i] = NDACC ? ndq : 0.f;
   f32x16 acc[2];
   acc[0] = zero16();
   acc[1] = zero16();
@@ -317,7 +324,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
       if constexpr (MASK) pv = (acc_row(i, h) > klim) ? 0.f : pv;
       cs[i] = pv;
     };
-    auto md = [&](int i) { cdp[i] = cs[i] * cdp[i]; };
+    auto md = [&](int i) { cdp[i] = NDACC ? cs[i] * cdp[i] : cs[i] * (cdp[i] + ndq); };
     auto vrow = [&](int kq) -> frag {
       return *FA_LDS(frag, smem + ((kq & 1) ? rn1 : rn0) + VOFF + (D / 32) * 512 * (4 * SUBN) + 512 * (kq >> 1));
     };
@@ -339,7 +346,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {   // slots 4-7: dP^T of the next sub-tile
       if constexpr (HN) {
-        if (kq == 0) A::mma_c(ndp, rv[0], dof[0], nd16);
+        if (kq == 0) A::mma_c(ndp, rv[0], dof[0], NDACC ? nd16 : zero16());
         else A::mma(ndp, rv[kq], dof[kq]);
         SB();
         if constexpr (LEAD == 2) {
@@ -465,15 +472,19 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
       g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
     }
   }
-  if (qvalid) {
-    float* row = dq + base + (size_t)qrow * ld;
+  // (the output address is formed HERE from opaque copies: computed before the loop, hipcc keeps it in three registers the
+  // masked build does not have and spills them around the loop)
+  int qr = qrow, hh = h;
+  asm volatile("" : "+v"(qr), "+v"(hh));
+  if (qr < N) {
+    float* row = dq + base + (size_t)qr * ld;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 val = {acc[dt][4 * g] * tau, acc[dt][4 * g + 1] * tau, acc[dt][4 * g + 2] * tau,
                      acc[dt][4 * g + 3] * tau};
-        *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * h) = val;
+        *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * hh) = val;
       }
   }
 }

@@ -29,4 +29,5 @@
 #include "fa_fwd.h"
 #include "fa_bwd_dkdv.h"
 #include "fa_bwd_dq.h"
+#include "fa_bwd_fused.h"
 #include "fa_aux.h"

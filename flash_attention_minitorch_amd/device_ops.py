@@ -44,9 +44,14 @@ def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None):
+# per-call kernel options of fa_mi355x_fwd_ex / fa_mi355x_bwd_ex (include/flash_attn_mi355x.h); all give the same results
+OPTS_PHASED = (4, 2, 2)          # the round-1 phased kernels instead of the MFMA-slot ones
+OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # dQ inside the key-stationary kernel, ordered hand-off (bf16, d = 64, non-causal, N % 256 == 0)
+
+
+def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None):
     """Forward.  Returns (out fp32, l, m): FA-1 -> l = sum exp(s - rowmax), m = rowmax;
-    FA-2 -> l = logsumexp, m = None."""
+    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*)."""
     bh, n, d = _check_inputs(q, k, v)
     lead = q.shape[:-2]
     if out is None:
@@ -55,25 +60,39 @@ def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None,
         l = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
     if variant == _lib.FA_VARIANT_FA1 and m is None:
         m = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.core().fa_mi355x_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), bh, n, d,
-                                         int(bool(causal)), variant, _DTYPES[q.dtype], _stream_ptr()))
+    arr, cnt = _lib.opts_array(opts)
+    _lib.check(_lib.core().fa_mi355x_fwd_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), bh, n, d,
+                                            int(bool(causal)), variant, _DTYPES[q.dtype], arr, cnt, _stream_ptr()))
     return out, l, m
 
 
-def bwd_workspace(q):
-    n, d = q.shape[-2], q.shape[-1]
-    bh = q.numel() // (n * d)
+def _workspace(bh, n, d, device):
     nbytes = _lib.core().fa_mi355x_bwd_workspace_bytes(bh, n, d)
-    return torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def bwd_workspace(q):
+    """Scratch for the backward of (.., N, d) tensors, sized by the library (fa_mi355x_bwd_workspace_bytes)."""
+    n, d = q.shape[-2], q.shape[-1]
+    return _workspace(q.numel() // (n * d), n, d, q.device)
+
+
+def bwd_status(workspace, q):
+    """Synchronous check of the one-pass backward's error word after a backward call that used ``workspace``; raises if a
+    hand-off wait timed out (fa_mi355x_bwd_status)."""
+    n, d = q.shape[-2], q.shape[-1]
+    st = ctypes.c_int(0)
+    _lib.check(_lib.core().fa_mi355x_bwd_status(_ptr(workspace), q.numel() // (n * d), n, d, ctypes.byref(st)))
+    return st.value
 
 
 STAGE_PREP, STAGE_DKDV, STAGE_DQ, STAGE_ALL = 1, 2, 4, 7
 
 
 def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2,
-                   workspace=None, grads=None, stages=STAGE_ALL):
+                   workspace=None, grads=None, stages=STAGE_ALL, opts=None):
     """Backward.  out: the forward's fp32 output.  Returns (dq, dk, dv) fp32.
-    ``stages`` restricts the call to some of its kernels (profiling only)."""
+    ``stages`` restricts the call to some of its kernels (profiling only); ``opts``: per-call kernel options (see OPTS_*)."""
     bh, n, d = _check_inputs(q, k, v, out_grad)
     if out.dtype != torch.float32 or out.shape != q.shape or not out.is_contiguous():
         raise ValueError("out must be the forward's contiguous float32 output")
@@ -82,10 +101,11 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
     if grads is None:
         grads = tuple(torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
     dq, dk, dv = grads
-    _lib.check(_lib.core().fa_mi355x_bwd_stages(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
-                                                _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(workspace), bh, n, d,
-                                                int(bool(causal)), variant, _DTYPES[q.dtype], int(stages),
-                                                _stream_ptr()))
+    arr, cnt = _lib.opts_array(opts)
+    _lib.check(_lib.core().fa_mi355x_bwd_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
+                                            _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(workspace), bh, n, d,
+                                            int(bool(causal)), variant, _DTYPES[q.dtype], int(stages), arr, cnt,
+                                            _stream_ptr()))
     return dq, dk, dv
 
 
@@ -111,7 +131,7 @@ def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2):
 def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2):
     """Backward on (B, N, H, d) tensors; returns (dq, dk, dv) in the same layout, fp32."""
     B, N, H, d = q.shape
-    ws = torch.empty(2 * B * H * N, dtype=torch.float32, device=q.device)
+    ws = _workspace(B * H, N, d, q.device)
     dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
     _lib.check(_lib.core().fa_mi355x_bwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
                                                 _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d,
@@ -149,7 +169,7 @@ def flash_attn_bwd_masked(q, k, v, out, out_grad, l, m, key_mask, causal=False, 
     """Backward of flash_attn_fwd_masked; returns (dq, dk, dv) fp32 (no gradient flows into the mask)."""
     _check_inputs(q, k, v, out_grad)
     B, H, N, d = _check_mask(key_mask, q)
-    ws = torch.empty(2 * B * H * N, dtype=torch.float32, device=q.device)
+    ws = _workspace(B * H, N, d, q.device)
     dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
     _lib.check(_lib.core().fa_mi355x_bwd_masked(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
                                                 _ptr(dv), _ptr(l), _ptr(m), _ptr(key_mask), _ptr(ws), B, H, N, d,
@@ -181,7 +201,7 @@ def flash_attn_bwd_dropout(q, k, v, out, out_grad, l, m, rate, seed, scale=1.0, 
     """Backward of flash_attn_fwd_dropout (same rate, seed, scale, mask); returns (dq, dk, dv) fp32."""
     _check_inputs(q, k, v, out_grad)
     B, H, N, d = _check_mask(key_mask, q) if key_mask is not None else q.shape
-    ws = torch.empty(2 * B * H * N, dtype=torch.float32, device=q.device)
+    ws = _workspace(B * H, N, d, q.device)
     dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
     _lib.check(_lib.core().fa_mi355x_bwd_dropout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
                                                  _ptr(dv), _ptr(l), _ptr(m), _ptr(key_mask), float(rate), float(scale),

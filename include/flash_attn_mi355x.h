@@ -77,8 +77,17 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m,
                   int batch, int N, int d, int causal, int variant, int dtype, void* stream);
 
-/* Bytes of scratch fa_mi355x_bwd needs (2 * batch * N floats: -L/tau and -rowsum(dO*O)). */
+/* Bytes of scratch fa_mi355x_bwd needs: 2 * batch * N floats (-L/tau and -rowsum(dO*O)) and, for shapes the one-pass
+ * backward takes (d = 64, N a multiple of 256), its flags and running dQ tiles (at most 32 MiB + 16.25 KiB).  Every
+ * backward entry point below expects a workspace of at least this size. */
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
+
+/* Synchronous check of the one-pass backward's error word in a workspace the last backward call used: *status = 0 if no
+ * hand-off wait timed out (always 0 for shapes / calls that ran the two-kernel backward).  Returns FA_ERR_HIP and a
+ * message when it is non-zero (the gradients of that call are then invalid).  The one-pass kernel is a persistent grid
+ * whose workgroups wait for each other: do not run two backward calls of such shapes concurrently on different streams
+ * of one device. */
+int fa_mi355x_bwd_status(const void* workspace, int batch, int N, int d, int* status);
 
 /* Backward on device pointers.  out: float (the forward's output); out_grad: dtype elements;
  * q_grad,k_grad,v_grad: float, overwritten; workspace: device scratch of the size above. */
@@ -96,6 +105,22 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
                          float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
                          void* workspace, int batch, int N, int d, int causal, int variant, int dtype, int stages,
                          void* stream);
+
+/* Forward / backward with per-call kernel options (no process-wide state): opts[0..nopts-1], nopts <= 8, 0 = default.
+ *   opts[0]  dK/dV kernel geometry: 1, 2, 4, 5 = the alternatives measured in profiles/README.md; 3 = the causal slot path
+ *   opts[1]  forward kernel: 2 = phased, 3 = slot kernel also under the causal mask, 6 = 128-key stages
+ *   opts[2]  dQ kernel: 1 / 2 / 4 = phased with 64- / 32-key tiles / 4 waves, 3 = slot kernel also under the causal mask
+ *   opts[3]  1 = waves 4-7 of the slot kernels run at s_setprio 1
+ *   opts[4]  2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
+ *            head by an ordered hand-off: five products as src/flash_attn2_bw.cu:94-247, no atomics, bitwise reproducible);
+ *            bf16, d = 64, non-causal, N a multiple of 256, stages containing both DKDV and DQ; other calls ignore it
+ * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
+ * library (FA_ERR_BAD_ARG).  `stages` as fa_mi355x_bwd_stages. */
+int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
+                     int causal, int variant, int dtype, const int* opts, int nopts, void* stream);
+int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                     float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
+                     int causal, int variant, int dtype, int stages, const int* opts, int nopts, void* stream);
 
 /* The same two operations on the layout the projection writes: SURVEY.md row f1.  minitorch's MultiHeadAttention
  * produces q, k, v as (B, N, H, d) views and then pays permute(0,2,1,3).contiguous() for each of them, and the
@@ -148,20 +173,16 @@ const char* fa_mi355x_last_error(void);
 /* Library version, e.g. "flash_attn_mi355x 0.1 gfx950". */
 const char* fa_mi355x_version(void);
 
-/* Tuning hook (in-process A/B benchmarks and tests only; every setting computes the same function).
- * key 0: dK/dV kernel, bf16 d <= 64 (0 default: at d = 64 the continuous slot pipeline when non-causal, MODE 3 = slot fast
- *        path + per-sub-slice path under the causal mask; 3 always MODE 3; 13 MODE 3 on register staging; 4 compiler-interleaved
- *        software pipeline; 1 plain; 2 four waves x 64 keys; 9 / 93 / 193 diagnostic builds with phase stamps, never timed)
- * key 1: forward, bf16 d = 64, FA-2 side output (0 default: slot-interleaved kernel, phased under the causal mask;
- *        2 always phased; 3 always slot; 6 the 128-key-stage slot build at two waves per SIMD)
- * key 2: dQ, bf16 (0 default: slot-interleaved kernel at d = 64 non-causal, else 32-key tiles; 1 = 64-key tiles; 2 = 32-key
- *        tiles, phased kernel; 3 always slot; 93 / 94 diagnostic builds, never timed)
- * key 3: 1 = waves 4-7 of the slot kernels run at s_setprio 1 (measured null; default 0).  Other keys are reserved. */
+/* ---- diagnostic build only (libflash_attn_mi355x_diag.so, compiled with -DFA_DIAG; used by tools/, never by the product
+ * path or the tests) ----
+ * fa_mi355x_set_tuning: process-wide defaults for the option slots of fa_mi355x_*_ex, plus the values the product library
+ * rejects: stamp builds (opts[0] = 9 / 93 / 193, opts[1] = 93, opts[2] = 93), the register-staging A/B build (opts[0] = 13), the
+ * barrier-less dQ timing ablation (opts[2] = 94, WRONG results) and opts[5] = timing ablations / stamps of the one-pass backward.
+ * fa_mi355x_debug_phase_cycles: copies the first n per-wave phase counters (8 per wave slot) a stamp build wrote. */
+#ifdef FA_DIAG
 int fa_mi355x_set_tuning(int key, int value);
-
-/* Profiling hook: per-wave cycle totals per loop phase written by a DIAGNOSTIC build (tuning key 0 = 9 / 93, key 2 = 93);
- * copies the first n counters (8 per wave slot) to host memory. */
 int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n);
+#endif
 
 /* Measurement aid: runs a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands on every CU (two waves per SIMD) for
  * at least min_ms and reports what the device SUSTAINS under power: dense bf16 TFLOP/s and the in-kernel clock (GHz).  bench.py

@@ -21,9 +21,15 @@ def built():
     return _lib
 
 
-def _declared_symbols():
+def _declared_symbols(diag=False):
+    """Entry points the header declares; those inside ``#ifdef FA_DIAG`` belong to the diagnostic build only."""
     text = open(os.path.join(ROOT, "include", "flash_attn_mi355x.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    diag_blocks = re.findall(r"#ifdef FA_DIAG(.*?)#endif", text, flags=re.S)
+    if diag:
+        text = "\n".join(diag_blocks)
+    else:
+        text = re.sub(r"#ifdef FA_DIAG.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b((?:launch_flash_attn|fa_mi355x)_\w+)\s*\(", text)))
 
 
@@ -31,7 +37,7 @@ def test_header_declares_expected_entry_points():
     syms = _declared_symbols()
     for s in ("launch_flash_attn_fw", "launch_flash_attn_bw", "fa_mi355x_fwd", "fa_mi355x_bwd",
               "fa_mi355x_bwd_workspace_bytes", "fa_mi355x_launch_fw_host", "fa_mi355x_launch_bw_host",
-              "fa_mi355x_bwd_stages", "fa_mi355x_fwd_layout", "fa_mi355x_bwd_layout", "fa_mi355x_fwd_masked", "fa_mi355x_bwd_masked", "fa_mi355x_fwd_dropout", "fa_mi355x_bwd_dropout", "fa_mi355x_last_error", "fa_mi355x_version", "fa_mi355x_set_tuning", "fa_mi355x_debug_phase_cycles", "fa_mi355x_measure_mfma_peak", "fa_mi355x_probe"):
+              "fa_mi355x_bwd_stages", "fa_mi355x_fwd_layout", "fa_mi355x_bwd_layout", "fa_mi355x_fwd_masked", "fa_mi355x_bwd_masked", "fa_mi355x_fwd_dropout", "fa_mi355x_bwd_dropout", "fa_mi355x_last_error", "fa_mi355x_version", "fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex", "fa_mi355x_bwd_status", "fa_mi355x_measure_mfma_peak", "fa_mi355x_probe"):
         assert s in syms
 
 
@@ -59,6 +65,70 @@ def test_backward_shims_export_reference_symbol(built, name):
     assert " T launch_flash_attn_bw" in out and "launch_flash_attn_fw" not in out
 
 
+def _device_kernels(path):
+    """(name, private_segment_fixed_size, vgpr_count) of every kernel in the gfx950 code object bundled in a built library."""
+    import struct
+    import tempfile
+    objcopy, readelf = "/opt/rocm/lib/llvm/bin/llvm-objcopy", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fat, path, os.path.join(td, "x")], check=True)
+        b = open(fat, "rb").read()
+        assert b.startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+        n = struct.unpack_from("<Q", b, 24)[0]
+        off, co = 32, None
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", b, off)
+            off += 24
+            triple = b[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple:
+                co = os.path.join(td, "dev.co")
+                open(co, "wb").write(b[o:o + sz])
+        assert co, "no gfx950 code object in " + path
+        notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True, check=True).stdout
+    out = []
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        out.append((name, scratch, vgpr))
+    return out
+
+
+def test_product_library_has_no_diagnostic_code_and_no_scratch(built):
+    """stamp builds, the barrier-less ablation and fa_mi355x_set_tuning live in the FA_DIAG build only, and no
+    kernel of the product library uses scratch memory.  One documented exception: the opt-in one-pass backward keeps <= 16 B per
+    lane for values that are live across (not inside) its sweep loop (csrc/fa_bwd_fused.h; hipcc's allocation, outside the loop)."""
+    path = built.lib_path("libflash_attn_mi355x.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    for s in _declared_symbols(diag=True):
+        assert s not in syms, s
+    assert "g_phase_cycles" not in syms
+    kernels = _device_kernels(path)
+    assert len(kernels) > 40
+    for name, scratch, vgpr in kernels:
+        assert vgpr <= 512
+        if "bwd_fused_kernel" in name:
+            assert scratch <= 16, (name, scratch)
+        else:
+            assert scratch == 0, (name, scratch)
+    # template arguments that only diagnostic instantiations carry: DIAG = 1 / 2 of the slot kernels, MODE 9 / 13 / 93 of dK/dV, ABL != 0
+    names = " ".join(k[0] for k in kernels)
+    assert not re.search(r"bwd_dkdv_kernelI\S*Li(9|13|93)ELb", names)
+    assert "bwd_dkdv_slot_kernelIDF16bLi64ELi1E" not in names and "bwd_dq_slot_kernelIDF16bLi64ELi1E" not in names
+    assert "bwd_dq_slot_kernelIDF16bLi64ELi2E" not in names
+    assert re.search(r"bwd_fused_kernelIDF16bLi64ELi0E", names) and not re.search(r"bwd_fused_kernelIDF16bLi64ELi[1-9]", names)
+
+
+def test_diagnostic_library_exports_the_diag_entry_points(built):
+    path = built.lib_path("libflash_attn_mi355x_diag.so")
+    assert os.path.exists(path)
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    for s in _declared_symbols(diag=True) + ["fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex"]:
+        assert s in syms, s
+
+
 def test_library_contains_gfx950_code_object(built):
     blob = open(built.lib_path(built.CORE_NAME), "rb").read()
     assert b"gfx950" in blob
@@ -67,9 +137,19 @@ def test_library_contains_gfx950_code_object(built):
 
 def test_argument_validation_without_gpu(built):
     core = built.core()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)
     assert core.fa_mi355x_version().decode().startswith("flash_attn_mi355x")
-    assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 64) == 2 * 64 * 4096 * 4
+    assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 128) == 2 * 64 * 4096 * 4
+    assert core.fa_mi355x_bwd_workspace_bytes(64, 4100, 64) == 2 * 64 * 4100 * 4      # not a one-pass shape
+    ws = core.fa_mi355x_bwd_workspace_bytes(64, 4096, 64)                              # + flags, pages and running dQ tiles
+    assert 2 * 64 * 4096 * 4 + 16 * 4096 * 256 <= ws <= 2 * 64 * 4096 * 4 + 33 * 2**20
     assert core.fa_mi355x_bwd_workspace_bytes(0, 4096, 64) == 0
+    # per-call options: diagnostic values are rejected by the product library before any HIP call
+    bad = (ctypes.c_int * 3)(93, 0, 0)
+    assert core.fa_mi355x_fwd_ex(one, one, one, one, one, one, 1, 16, 64, 0, 2, 0, bad, 3, null) == 1
+    assert b"diagnostic" in core.fa_mi355x_last_error()
+    assert core.fa_mi355x_fwd_ex(one, one, one, one, one, one, 1, 16, 64, 0, 2, 0, None, 9, null) == 1
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)
     # bad sizes / null pointers / unsupported d are rejected before any HIP call

@@ -243,18 +243,11 @@ def test_slot_kernels_block_and_ring_boundaries(dev, N, causal):
     tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
     tol = TOLBF_CAUSAL if causal else TOLBF
     ref = oracle_heads(*arrs, causal, range(BH))
-    core = _lib.core()
-    try:
-        outs = {}
-        for tag, knobs in (("slot", (0, 3, 3)), ("phased", (4, 2, 2))):   # 3 forces the slot kernels under the causal mask too
-            for key, val in zip((0, 1, 2), knobs):
-                core.fa_mi355x_set_tuning(key, val)
-            o, l, m = dev.flash_attn_fwd(tq, tk, tv, causal=causal)
-            dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, m, causal=causal)
-            outs[tag] = [to_np(x) for x in (o, l, dq, dk, dv)]
-    finally:
-        for key in (0, 1, 2):
-            core.fa_mi355x_set_tuning(key, 0)
+    outs = {}
+    for tag, opts in (("slot", (0, 3, 3)), ("phased", dev.OPTS_PHASED)):   # 3 forces the slot kernels under the causal mask too
+        o, l, m = dev.flash_attn_fwd(tq, tk, tv, causal=causal, opts=opts)
+        dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, m, causal=causal, opts=opts)
+        outs[tag] = [to_np(x) for x in (o, l, dq, dk, dv)]
     for nm, got in zip(("o", "L", "dq", "dk", "dv"), outs["slot"]):
         assert np.all(np.isfinite(got)), nm
         assert maxabs(got, ref[nm]) < tol, (nm, maxabs(got, ref[nm]))
@@ -367,18 +360,93 @@ def test_forward_slot_kernel_d128(dev, N):
     arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(3)]
     tq, tk, tv = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
     ro, rL, _, _ = oracle.dense_attention_fw(*arrs)
-    core = _lib.core()
-    try:
-        core.fa_mi355x_set_tuning(1, 0)
-        o_s, l_s, _ = dev.flash_attn_fwd(tq, tk, tv)
-        core.fa_mi355x_set_tuning(1, 2)
-        o_p, l_p, _ = dev.flash_attn_fwd(tq, tk, tv)
-    finally:
-        core.fa_mi355x_set_tuning(1, 0)
+    o_s, l_s, _ = dev.flash_attn_fwd(tq, tk, tv)
+    o_p, l_p, _ = dev.flash_attn_fwd(tq, tk, tv, opts=(0, 2))
     assert maxabs(to_np(o_s), ro) < TOLBF and maxabs(to_np(l_s), rL) < TOLBF
     # the two kernels set their softmax reference on 32 vs 64 keys, so P is rounded to bf16 at different scales:
     # each is within TOLBF of the oracle, their difference within the sum
     assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF
+
+
+@pytest.mark.parametrize("BH,N", [(1, 256), (3, 512), (5, 768), (2, 2048), (20, 1024)])
+def test_one_pass_backward_matches_oracle_and_two_kernel_path(dev, BH, N):
+    """The opt-in one-pass backward (csrc/fa_bwd_fused.h: dQ formed in the key-stationary kernel, summed across the N/256
+    key-block workgroups of a head by the ordered hand-off; src/flash_attn2_bw.cu:94-247 is the single pass it matches): against
+    the fp64 oracle (1e-3), against the default two-kernel backward, bitwise repeatable, no hand-off timeout.  BH = 20 at
+    N = 1024 makes groups walk several heads (the flags count on across heads); N = 768 has a chain length that does not
+    divide 32 (groups span XCDs)."""
+    import torch
+    rng = np.random.default_rng(9100 + N + BH)
+    d = 64
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    o, l, _ = dev.flash_attn_fwd(tq, tk, tv)
+    ws = dev.bwd_workspace(tq)
+    one = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws, opts=dev.OPTS_ONE_PASS_BWD)]
+    assert dev.bwd_status(ws, tq) == 0
+    again = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws, opts=dev.OPTS_ONE_PASS_BWD)]
+    two = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws)]
+    heads = range(BH) if BH * N <= 4096 else range(0, BH, max(1, BH // 3))
+    ref = oracle_heads(*arrs, False, heads)
+    for nm, a, b, c in zip(("dq", "dk", "dv"), one, again, two):
+        assert np.all(np.isfinite(a)), nm
+        assert np.array_equal(a, b), nm                       # fixed summation order: bitwise repeatable
+        assert maxabs(a, c) < 0.5 * TOLBF, (nm, maxabs(a, c))  # same arithmetic per element, another summation order
+        assert maxabs(a[list(heads)], ref[nm]) < TOLBF, (nm, maxabs(a[list(heads)], ref[nm]))
+
+
+def test_one_pass_backward_at_metric_shape(dev):
+    """B=8, H=8, N=4096, d=64 (BASELINE.json's metric shape): sampled heads against the oracle, size-independent properties."""
+    import torch
+    BH, N, d = 64, 4096, 64
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    mk = lambda: ((torch.rand((BH, N, d), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    tq, tk, tv, tdo = mk(), mk(), mk(), mk()
+    o, l, _ = dev.flash_attn_fwd(tq, tk, tv)
+    ws = dev.bwd_workspace(tq)
+    dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws, opts=dev.OPTS_ONE_PASS_BWD)
+    assert dev.bwd_status(ws, tq) == 0
+    dq2, dk2, dv2 = (x.clone() for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws))
+    for nm, a, b in (("dq", dq, dq2), ("dk", dk, dk2), ("dv", dv, dv2)):
+        assert float((a - b).abs().max()) < 0.5 * TOLBF, nm
+    # sum_q dQ o Q = sum_k dK o K per head (both equal sum dS o S / tau-free identity of the softmax backward)
+    lhs = (dq * tq.float()).sum(dim=(1, 2)).cpu().numpy()
+    rhs = (dk * tk.float()).sum(dim=(1, 2)).cpu().numpy()
+    assert np.max(np.abs(lhs - rhs)) < 2e-2 * max(1.0, float(np.max(np.abs(lhs))))
+    heads = [0, 29, 63]
+    arrs = [to_np(t.float())[heads] for t in (tq, tk, tv, tdo)]
+    ref = oracle_heads(*arrs, False, range(len(heads)))
+    for nm, a in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert maxabs(to_np(a)[heads], ref[nm]) < TOLBF, nm
+
+
+@pytest.mark.parametrize("dtype,d", [("f32", 64), ("bf16", 128), ("bf16", 32)])
+@pytest.mark.parametrize("N", [33, 200])
+def test_ragged_tail_with_very_negative_logsumexp(dev, dtype, d, N):
+    """keys past N in the last tile of the phased dQ kernel read K = 0, so P = exp(-L); with a row logsumexp
+    below about -88 that is +inf and dS = inf * 0 poisoned the row's dQ.  q = -s * k drives every score far below -100."""
+    import torch
+    rng = np.random.default_rng(9300 + N + d)
+    BH = 2
+    k = rand_u(rng, (BH, N, d)) + np.float32(1.5)            # all keys alike and of one sign: every score is very negative
+    q = (-16.0 * np.ones((BH, N, d))).astype(np.float32) * np.abs(rand_u(rng, (BH, N, d)) + np.float32(1.5))
+    v, do = rand_u(rng, (BH, N, d)), rand_u(rng, (BH, N, d))
+    arrs = [q, k, v, do]
+    if dtype == "bf16":
+        arrs = [oracle.bf16_round(a) for a in arrs]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", tdt) for a in arrs)
+    ref = oracle_heads(*arrs, False, range(BH))
+    assert np.max(ref["L"]) < -100.0
+    o, l, m = dev.flash_attn_fwd(tq, tk, tv)
+    dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, m)
+    # |q| is up to 40 here, so the bound is relative to each tensor's magnitude (bf16: P, dS enter the second MFMA at 2^-9 relative)
+    tol = 8 * TOLBF if dtype == "bf16" else TOL32
+    for nm, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+        g = to_np(got)
+        assert np.all(np.isfinite(g)), nm
+        scale = max(1.0, float(np.max(np.abs(ref[nm]))))
+        assert maxabs(g, ref[nm]) < tol * scale, (nm, maxabs(g, ref[nm]), scale)
 
 
 def test_random_shapes_bf16(dev):

@@ -4,6 +4,8 @@ difference of their outputs.  usage: python tools/bench_fwd_d128.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os
+_os.environ["FA_MI355X_DIAG"] = "1"   # tools use the diagnostic build (set_tuning, stamps, ablations)
 from flash_attention_minitorch_amd import device_ops, _lib
 core = _lib.core()
 def t_ms(fn, iters=5):

@@ -4,6 +4,8 @@ interleaved rounds, per kernel.  usage: python tools/bench_prio.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os
+_os.environ["FA_MI355X_DIAG"] = "1"   # tools use the diagnostic build (set_tuning, stamps, ablations)
 from flash_attention_minitorch_amd import device_ops, _lib
 B, H, N, d = 8, 8, 4096, 64
 BH = B * H

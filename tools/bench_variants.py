@@ -4,6 +4,8 @@ usage: bench_variants.py [B H N d] [--knobs 0:0,1,2 1:0,1 2:0,1]"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os
+_os.environ["FA_MI355X_DIAG"] = "1"   # tools use the diagnostic build (set_tuning, stamps, ablations)
 from flash_attention_minitorch_amd import device_ops, _lib
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]

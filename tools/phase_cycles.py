@@ -5,6 +5,8 @@ usage: phase_cycles.py [9 | 93]     9 = phased kernel, 93 = slot-interleaved ker
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+import os as _os
+_os.environ["FA_MI355X_DIAG"] = "1"   # tools use the diagnostic build (set_tuning, stamps, ablations)
 from flash_attention_minitorch_amd import device_ops, _lib
 B, H, N, d = 8, 8, 4096, 64
 BH = B * H
