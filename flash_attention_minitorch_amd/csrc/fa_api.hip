@@ -91,18 +91,18 @@ int device_cus() {
 
 template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
-                   fa::Layout lay, int causal, int variant, float tau, hipStream_t st) {
+                   fa::Layout lay, int causal, int variant, float tau, hipStream_t st, int only_qb = -1) {
   const int nqb = (N + 127) / 128;
-  const int nblk = causal ? (nqb + 1) / 2 : nqb;   // causal: query blocks p and nqb-1-p share a workgroup
+  const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
   if (lay.drop_thr)   // dropout on P (and the key mask, staged as zeros when absent)
     hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 2>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
+                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, only_qb);
   else if (lay.kmask)   // additive key mask: staged per tile, enters S^T as the accumulator input
     hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 1>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
+                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, only_qb);
   else
     hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
+                       (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, only_qb);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
@@ -114,7 +114,8 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
     // FA-2 side output, bf16, d = 64 / 128, non-causal: slot-interleaved three-deep pipeline.  Under the causal mask the phased
     // kernel (128-query workgroups, per-wave tile skipping) measured 3.6 % faster, so it keeps that case; tuning key 1:
     // 2 = always phased, 3 = always slot.
-    if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3) && !lay.kmask && !lay.drop_thr) {
+    // (N < 64: every row has few keys and takes the phased kernel's split-operand path)
+    if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3) && !lay.kmask && !lay.drop_thr && N >= 64) {
       const int nqb = (N + 255) / 256;
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
@@ -142,6 +143,9 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
         hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
+        // under the causal mask rows 0..63 see fewer than 64 keys: the slot kernel has no split-operand path, so the phased
+        // kernel redoes query block 0 (one small workgroup per batch*head) behind it
+        if (causal) return fwd_launch_cfg<T, D, 64, 1>(q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st, 0);
         return FA_OK;
       }
     }
@@ -173,18 +177,18 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
 
 template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
+              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int only_qb = -1) {
   const int nqb = (N + 127) / 128;
-  const int nblk = causal ? (nqb + 1) / 2 : nqb;   // causal: query blocks p and nqb-1-p share a workgroup
+  const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
   if (lay.drop_thr)
     hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 2>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb);
   else if (lay.kmask)
     hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 1>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb);
   else
     hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb);
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
@@ -287,8 +291,9 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = FA_OK;
       }
 #endif
-      else if (D == 64 && !causal && tun.v[0] == 0 && !lay.drop_thr) {
-        // d = 64, non-causal default: the continuous slot pipeline (no drain at stage boundaries, three-slot LDS-DMA ring)
+      else if (D == 64 && !causal && tun.v[0] == 0 && !lay.drop_thr && !lay.kmask && N >= 64) {
+        // d = 64, non-causal default: the continuous slot pipeline (no drain at stage boundaries, three-slot LDS-DMA ring);
+        // rows thinned by a key mask or N < 64 go to the kernel below, whose per-sub-slice path splits P and dS
         const int nkb = (N + 255) / 256;
         {
           hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
@@ -350,7 +355,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
       if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || (causal && tun.v[2] != 3))   // key mask and dropout live in the
+      else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || (causal && tun.v[2] != 3) || N < 64)   // key mask and dropout live in the
         // phased kernel, which is also 1 % faster under the causal mask (tuning key 2 = 3 forces the slot kernel)
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
 #ifdef FA_DIAG
@@ -359,8 +364,11 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       else if (tun.v[2] == 93)   // phase stamps (never timed)
         rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
 #endif
-      else
+      else {
         rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+        // forced onto a causal launch: rows 0..63 (few keys) are redone by the phased kernel's split-operand path (query block 0)
+        if (!rc && causal) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);
+      }
     } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
       if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);

@@ -106,6 +106,22 @@ template <> struct Atom<bf16_t> {
     }
     return __builtin_bit_cast(frag, u);
   }
+  // What pack() rounded away: registers 8s..8s+7 minus their bf16 images, as a second fragment.  A product issued once with
+  // pack() and once with pack_lo() carries the operand at 16 significant bits: rows with few admissible keys (the first rows
+  // under the causal mask, N < 64, most keys dropped by a mask) hold P, dS of order 1 whose 2^-9 rounding is not averaged out.
+  static FA_DEV frag pack_lo(const f32x16& x, int s, const frag& hi) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    const u4 hu = __builtin_bit_cast(u4, hi);
+    u4 u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float h0 = __uint_as_float(hu[j] << 16), h1 = __uint_as_float(hu[j] & 0xffff0000u);
+      f32x2 pr = {x[8 * s + 2 * j] - h0, x[8 * s + 2 * j + 1] - h1};
+      u[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+    }
+    return __builtin_bit_cast(frag, u);
+  }
+  static constexpr bool SPLITS = true;
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
@@ -161,6 +177,8 @@ template <> struct Atom<float> {
     for (int j = 0; j < 8; ++j) f[j] = x[8 * s + j];
     return f;
   }
+  static FA_DEV frag pack_lo(const f32x16&, int, const frag&) { return zero(); }   // pack() is exact
+  static constexpr bool SPLITS = false;
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);

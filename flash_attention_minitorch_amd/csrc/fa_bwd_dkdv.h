@@ -168,6 +168,11 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
   }
+  // Stages whose query rows may see fewer than 64 admissible keys (the first rows under the causal mask, N < 64, a key mask or
+  // dropout thinning the row) take the per-sub-slice path, where P and dS enter the dV / dK products as two bf16 fragments each
+  // (Atom::pack_lo): on such rows their 2^-9 rounding is not averaged out (bf16 only; wave-uniform).
+  const bool thin = A::SPLITS && (HD || lay.kmask != nullptr);
+  auto careful_stage = [&](int qi_) { return A::SPLITS && (thin || (causal ? qi_ * QS < 64 : N < 64)); };
   auto slice = [&](auto par, int qi) {
     constexpr int PAR = decltype(par)::value;
     const bool more = qi + 1 < nqi;
@@ -188,7 +193,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     // LDS fragments are requested four slots before the MFMA that consumes them.
     constexpr bool SLOT = !HD && (MODE == 3 || MODE == 93 || MODE == 13) && NSUB == 4 && D == 64 && KT == 1 && sizeof(T) == 2;
     if constexpr (SLOT) {
-      const bool fast3 = (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
+      const bool fast3 = !careful_stage(qi) && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
       if (fast3) {
         f32x16 sA, dpA, sB, dpB, cS, cD;
         frag pf0, pf1, df0, df1, rq[4], rdo[4], tf[4];
@@ -320,8 +325,8 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     // ---- software-pipelined fast path (stage fully unmasked): S, dP of sub-slice i+1 are issued before the
     // exp / mul / pack work of sub-slice i, so one wave has independent MFMA and VALU streams to interleave.
     constexpr bool PIPE = !HD && MODE == 0 && NSUB == 4 && D <= 64;   // (needs ~250 VGPRs at d = 64; not for d = 128)
-    const bool fast = PIPE && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
-    const bool fast_slot = SLOT && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);
+    const bool fast = PIPE && !careful_stage(qi) && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);   // wave-uniform
+    const bool fast_slot = SLOT && !careful_stage(qi) && (kw0 < N) && (!causal || qi * QS >= kw0 + KPW - 1);
     if (fast_slot) {
     } else if (fast) {
       auto mfma1 = [&](auto subc, f32x16(&s)[KT], f32x16(&dp)[KT]) {
@@ -492,6 +497,27 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
               A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
             }
           }
+        if (thin || (A::SPLITS && (causal ? qi0 < 64 : N < 64))) {   // rows with few admissible keys: what the bf16 rounding of P, dS dropped
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            frag pl[KT], dl[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              pl[kt] = A::pack_lo(s[kt], s2, pf[kt][s2]);
+              dl[kt] = A::pack_lo(dp[kt], s2, dsf[kt][s2]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
+              const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
+#pragma unroll
+              for (int kt = 0; kt < KT; ++kt) {
+                A::mma(acc_dv[dt][kt], adoT, pl[kt]);
+                A::mma(acc_dk[dt][kt], aqT, dl[kt]);
+              }
+            }
+          }
+        }
         if constexpr (DIAG) { t0 = stamp(); ph[3] += t0 - t3; }
       }
     }

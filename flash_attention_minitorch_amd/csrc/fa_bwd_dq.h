@@ -13,8 +13,8 @@ template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4>
 __global__ void __launch_bounds__(64 * NWQ)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
-              int BH, Layout lay, int causal, float tau) {
-  using A = Atom<T>;
+              int BH, Layout lay, int causal, float tau, int only_qb = -1) {
+  using A = Atom<T>;   // only_qb: as fwd_kernel's
   typedef typename A::frag frag;
   constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
   constexpr int KC = D / 16, KT = BN / 32, DT = D / 32;
@@ -26,14 +26,15 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // causal launches pair query block p with block nqb-1-p in one workgroup (see fwd_kernel): uniform work per workgroup
-  const int nblk = causal ? (nqb + 1) / 2 : nqb;
+  const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);
   int bh, pblk;
   map_block(blockIdx.x, BH, nblk, bh, pblk);
-  const int npass = (causal && pblk != nqb - 1 - pblk) ? 2 : 1;
+  const int npass = (only_qb < 0 && causal && pblk != nqb - 1 - pblk) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qb = causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk;
+  const int qb = only_qb >= 0 ? only_qb : (causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk);
   const int q0 = qb * (32 * NWQ) + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
+  const bool careful = A::SPLITS && (HM || HD || (causal ? q0 < 64 : N < 64));   // wave-uniform: see fwd_kernel
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
@@ -162,6 +163,17 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2)
             A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dsf[kt][s2]);
+      if (careful) {   // rows with few admissible keys: K^T dS^T once more with what the bf16 rounding of dS dropped
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const frag dl = A::pack_lo(dp[kt], s2, dsf[kt][s2]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+              A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dl);
+          }
+      }
     }
     if (more) {
       sk.store(smem + (PAR ^ 1) * TB);

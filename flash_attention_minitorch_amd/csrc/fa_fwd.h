@@ -21,7 +21,9 @@ template <typename T, int D, int BN, int WPE, int FEAT = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
            float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, Layout lay, int causal,
-           int aux_mode, float tau) {
+           int aux_mode, float tau, int only_qb = -1) {
+  // only_qb >= 0: one workgroup per (batch*head) that handles just that 128-query block (the launcher re-runs block 0 behind a
+  // slot kernel forced onto a causal launch: the slot kernels have no split-operand path for the rows with few keys)
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
@@ -35,14 +37,17 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
   // Causal launches pair query block p with block nqb-1-p in one workgroup (heavy one first): every workgroup then sweeps the
   // same number of key tiles and the grid has no long tail (the launcher sizes the grid with fwd_blocks()).
-  const int nblk = causal ? (nqb + 1) / 2 : nqb;
+  const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);
   int bh, pblk;
   map_block(blockIdx.x, BH, nblk, bh, pblk);
-  const int npass = (causal && pblk != nqb - 1 - pblk) ? 2 : 1;
+  const int npass = (only_qb < 0 && causal && pblk != nqb - 1 - pblk) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
-  const int qb = causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk;
+  const int qb = only_qb >= 0 ? only_qb : (causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk);
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
+  // wave-uniform: this wave's rows may see fewer than 64 admissible keys (or a mask / dropout thins them): operands that the
+  // second product takes in bf16 are then split into two fragments (Atom::pack_lo).  bf16 only: the fp32 atom is exact.
+  const bool careful = A::SPLITS && (HM || HD || (causal ? q0 < 64 : N < 64));
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
@@ -200,6 +205,17 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt)
             A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pf[kt][s2]);
+      if (careful) {   // rows with few admissible keys: P.V once more with what the bf16 rounding of P dropped
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const frag pl = A::pack_lo(s[kt], s2, pf[kt][s2]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+              A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pl);
+          }
+      }
     }
     if (more) {
       sk.store(smem + (PAR ^ 1) * TB);

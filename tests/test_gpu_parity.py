@@ -2,14 +2,11 @@
 vectors.  Tolerances (max-abs, stated per SURVEY.md section 8d):
   fp32 path : 1e-4 on O, dQ, dK, dV, L; FA-1 m equals the row max within 1e-5
               (the reference's own GPU tests use 1e-3 fw / 1e-2 bw: kernel_tests/test_flashattn_fw.py:23, _bw.py:19)
-  bf16 path : 1e-3 on fp32-stored O, dQ, dK, dV, L vs the fp64 oracle on the SAME bf16-rounded inputs (north_star).
-              Causal: 4e-3.  P and dS enter the second MFMA of each product as bf16 (relative quantisation
-              2^-9 = 1.95e-3).  A causal row i attends to only i+1 keys, so the first rows carry P, dS of order 1 that
-              are not averaged over many keys: |err O| <= 2^-9 * max|V|, and key 0 collects P_i0 ~ 1/(i+1) from every
-              early row, so dV_0, dK_0 see a harmonic sum of such terms (measured up to 3.3e-3 for |V|,|dO| <= 1).
-              Non-causal rows with >= 64 keys each stay under 1e-3; with fewer keys per row (N < 64, or most keys
-              dropped by a key mask) the same non-averaged quantisation applies as for early causal rows (a 300-case
-              random sweep, tools/fuzz_gpu.py, saw up to 1.7e-3 on dV at N < 40 and 4.9e-3 under causal + key mask).
+  bf16 path : 1e-3 on fp32-stored O, dQ, dK, dV, L vs the fp64 oracle on the SAME bf16-rounded inputs (north_star), causal and
+              not.  P and dS enter the second MFMA of each product as bf16 (relative quantisation 2^-9 = 1.95e-3); rows with
+              many keys average that out.  Rows with fewer than 64 admissible keys (the first rows under the causal mask,
+              N < 64, rows thinned by a key mask or dropout) do not: there the kernels issue the product twice, with P / dS
+              split into two bf16 fragments (Atom::pack_lo; round 1 had loosened these cases to 4e-3 instead).
 """
 import os
 
@@ -23,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 TOL32 = 1e-4
 TOLBF = 1e-3
-TOLBF_CAUSAL = 4e-3
+TOLBF_CAUSAL = TOLBF   # round 1: 4e-3 (see the header); kept as a name so the causal cases stay visible
 FLT_MAX = np.finfo(np.float32).max
 
 
@@ -365,7 +362,7 @@ def test_forward_slot_kernel_d128(dev, N):
     assert maxabs(to_np(o_s), ro) < TOLBF and maxabs(to_np(l_s), rL) < TOLBF
     # the two kernels set their softmax reference on 32 vs 64 keys, so P is rounded to bf16 at different scales:
     # each is within TOLBF of the oracle, their difference within the sum
-    assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF
+    assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF   # (see the comment above)
 
 
 @pytest.mark.parametrize("BH,N", [(1, 256), (3, 512), (5, 768), (2, 2048), (20, 1024)])

@@ -31,7 +31,7 @@ for ci in range(cases):
     # (<= 1e-3); rows with few keys do not -- early causal rows, N < 64, heavily masked rows (tests/test_gpu_parity.py header)
     few_keys = causal or N < 64 or mode == "mask"
     # (the causal figure is a ~3-sigma tail of zero-mean rounding noise on key 0's dV: 4.0-4.1e-3 appears about once in 300 cases)
-    tol = ((6e-3 if (causal and mode == "mask") else 5e-3) if few_keys else 1e-3) if dtype == "bf16" else 1e-4
+    tol = 1e-3 if dtype == "bf16" else 1e-4   # round 2: no few-key exemption (split P / dS fragments on such rows)
     t = [torch.from_numpy(a).to("cuda", tdt) for a in arrs]
     desc = (ci, dtype, d, N, B, H, causal, variant, mode)
     try:
