@@ -14,11 +14,19 @@ region); the one RCCL all-gather of O the north star describes is timed separate
 
 FLOP accounting: fw = 4*B*H*N^2*d, bw = 10*B*H*N^2*d; softmax flops not counted.
 
+    python bench.py --config c4 [--gpus N ...]     BASELINE.json configs[4]: FA-2 forward, bf16, B=128 H=16 N=4096 d=128, the
+                                                   batch*head axis cut over the ranks (strong scaling), with the RCCL gather
+
 Extra objects on the JSON line:
   roofline     -- dominant kernel (longest average launch): algorithmic FLOPs per launch / HIP-event duration,
                   against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline -- the oracle's NumPy fp32 vanilla attention fw+bw (oracle/attention_ref.py), timed on this host on a
                   bounded sample of heads of the same workload (rank 0, --gpus 1 only).
+  vs_vanilla   -- the reference's own comparison (README.md:7, kernel_tests/test_flashattn_time.py) on this GPU: materialised-S
+                  attention in torch-ROCm (tools/vanilla_gpu.py) beside the flash path, forward and forward+backward.
+  variants     -- [total, fw, bw] ms of the reference's three operator variants (FA-1, FA-1 "causal", FA-2; all called with
+                  causal_mask = True, fp32, as kernel_tests/test_flashattn_time.py:64-93 times them) and of BASELINE.json
+                  configs[1..3] (rank 0, --gpus 1 only; after the timed region).
 """
 import argparse
 import json
@@ -50,13 +58,180 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-sustained-peak", action="store_true")
+    ap.add_argument("--config", choices=["metric", "c4"], default="metric",
+                    help="metric: BASELINE.json's headline shape (default); c4: configs[4], forward sharded over the ranks")
+    ap.add_argument("--no-extras", action="store_true", help="skip vs_vanilla / variants (rank 0, --gpus 1 only)")
     ap.add_argument("--phased", action="store_true",
                     help="profiling A/B only: run the phased (round-1 v5) kernels instead of the MFMA-slot ones")
     return ap.parse_args()
 
 
+def run_extras(torch, device_ops, q, k, v, do, causal):
+    """vs_vanilla at the bench shape and the per-variant [total, fw, bw] table; a few seconds, after the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import vanilla_gpu as vg
+    from flash_attention_minitorch_amd import _lib
+    BH, N, d = q.shape
+    out = {}
+    # --- flash vs vanilla (bf16 matmuls, fp32 softmax: the strongest vanilla torch offers) at this run's shape
+    o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal)
+    ws = device_ops.bwd_workspace(q)
+    grads = tuple(torch.empty(q.shape, dtype=torch.float32, device="cuda") for _ in range(3))
+    f_fw = lambda: device_ops.flash_attn_fwd(q, k, v, causal, out=o, l=L)
+
+    def f_fwbw():
+        f_fw()
+        device_ops.flash_attn_bwd(q, k, v, o, do, L, None, causal, workspace=ws, grads=grads)
+
+    v_fw = lambda: vg.vanilla_attention(q, k, v, causal)
+    v_fwbw = lambda: vg.vanilla_fw_bw(q, k, v, do, causal)
+    r = {"vanilla_fw_ms": vg.time_ms(v_fw, 3), "flash_fw_ms": vg.time_ms(f_fw, 10),
+         "vanilla_fwbw_ms": vg.time_ms(v_fwbw, 3), "flash_fwbw_ms": vg.time_ms(f_fwbw, 10)}
+    r["max_abs_diff_fw"] = float((v_fw().float() - o).abs().max())
+    r["speedup_fw"] = r["vanilla_fw_ms"] / r["flash_fw_ms"]
+    r["speedup_fwbw"] = r["vanilla_fwbw_ms"] / r["flash_fwbw_ms"]
+    r["vanilla"] = "torch-ROCm materialised S: bf16 matmuls (hipBLASLt), fp32 softmax, autograd backward; device resident"
+    out["vs_vanilla"] = {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in r.items()}
+    torch.cuda.empty_cache()
+
+    # --- per-variant [total, fw, bw]
+    def three(B, H, N_, d_, tdt, variant, caus):
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        mk = lambda: ((torch.rand((B * H, N_, d_), device="cuda", generator=gen) - 0.5) * 2).to(tdt)
+        qq, kk, vv, dd = mk(), mk(), mk(), mk()
+        oo, ll, mm = device_ops.flash_attn_fwd(qq, kk, vv, caus, variant)
+        w2 = device_ops.bwd_workspace(qq)
+        gg = tuple(torch.empty(qq.shape, dtype=torch.float32, device="cuda") for _ in range(3))
+        fw = lambda: device_ops.flash_attn_fwd(qq, kk, vv, caus, variant, out=oo, l=ll, m=mm)
+        bw = lambda: device_ops.flash_attn_bwd(qq, kk, vv, oo, dd, ll, mm, caus, variant, workspace=w2, grads=gg)
+        tf, tb = vg.time_ms(fw, 10, 3), vg.time_ms(bw, 10, 3)
+        cf = 0.5 if caus else 1.0
+        fl_fw, fl_bw = 4.0 * B * H * N_ * N_ * d_ * cf, 10.0 * B * H * N_ * N_ * d_ * cf
+        return {"ms_total_fw_bw": [round(tf + tb, 4), round(tf, 4), round(tb, 4)],
+                "tflops_total_fw_bw": [round((fl_fw + fl_bw) / (tf + tb) / 1e9, 1), round(fl_fw / tf / 1e9, 1), round(fl_bw / tb / 1e9, 1)]}
+
+    f32, bf = torch.float32, torch.bfloat16
+    FA1, FA2 = _lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2
+    out["variants"] = {
+        "what": "[total, fw, bw]; device resident; the first three rows are the reference's timing harness "
+                "(kernel_tests/test_flashattn_time.py:64-93: B=8 H=8 d=64, causal_mask=True, fp32) at N=2048",
+        "flash_attn (FA-1) fp32 causal B8 H8 N2048 d64": three(8, 8, 2048, 64, f32, FA1, True),
+        "flash_attn_causal (FA-1) fp32 causal B8 H8 N2048 d64": three(8, 8, 2048, 64, f32, FA1, True),
+        "flash_attn2 (FA-2) fp32 causal B8 H8 N2048 d64": three(8, 8, 2048, 64, f32, FA2, True),
+        "configs[1] FA-1 fp32 B8 H8 N1024 d64": three(8, 8, 1024, 64, f32, FA1, False),
+        "configs[2] FA-1 fp32 B8 H8 N2048 d64": three(8, 8, 2048, 64, f32, FA1, False),
+        "configs[3] FA-2 bf16 B16 H16 N4096 d128": three(16, 16, 4096, 128, bf, FA2, False),
+        "metric shape causal FA-2 bf16 B8 H8 N4096 d64": three(8, 8, 4096, 64, bf, FA2, True),
+    }
+    return out
+
+
+def main_c4(args):
+    """BASELINE.json configs[4]: FlashAttention-2 forward, bf16, B=128 H=16 N=4096 d=128, batch*head sharded over the ranks
+    (2048 pairs / world each: strong scaling), one RCCL all-gather of O; also the gather hidden under the compute."""
+    import torch
+    import torch.distributed as dist
+    from flash_attention_minitorch_amd import device_ops, sharded
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("FA_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    backend = os.environ.get("FA_BENCH_BACKEND", "nccl")
+    if backend == "nccl":   # (a one-rank group at --gpus 1: the same collective calls run everywhere)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    B, H, N, d = 128, 16, 4096, 128
+    BH_total = B * H
+    b0, b1 = sharded.shard_range(BH_total, rank, world)
+    bh = b1 - b0
+    gen = torch.Generator(device="cuda").manual_seed(2004 + rank)
+    mk = lambda: ((torch.rand((bh, N, d), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    q, k, v = mk(), mk(), mk()
+    out = torch.empty((bh, N, d), dtype=torch.float32, device="cuda")
+    L = torch.empty((bh, N), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps
+
+    steps, warmup = args.steps, args.warmup
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+    it = [0]
+
+    def fwd():
+        device_ops.flash_attn_fwd(q, k, v, False, out=out, l=L)
+
+    def fwd_ev():
+        e = ev[it[0] % steps]
+        e[0].record()
+        fwd()
+        e[1].record()
+        it[0] += 1
+
+    for _ in range(warmup):
+        fwd()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fwd_ev()
+    barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    sec = float(tt.item()) / steps
+    kern_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+    gsteps = max(2, min(5, steps))
+    gather_s = timed(lambda: sharded.all_gather_bh(out, BH_total), gsteps, 1)
+    chunks = 4 if bh % 4 == 0 else 1
+    over_s = timed(lambda: sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH_total, False, chunks=chunks), gsteps, 1)
+    flops_total = 4.0 * BH_total * N * N * d
+    flops_rank = 4.0 * bh * N * N * d
+    if rank == 0:
+        ach = flops_rank / (kern_ms * 1e-3) / 1e12
+        line = {
+            "metric": "attn fw TFLOP/s at configs[4] (B=128,H=16,N=4096,d=128, batch*head sharded); % MFMA roofline",
+            "value": round(flops_total / sec / 1e12, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[4]: FlashAttention-2 forward, B={B} H={H} N={N} d={d}, bf16 in / fp32 out, "
+                                   f"non-causal, {BH_total} (batch, head) pairs cut into {world} contiguous slices ({bh} on rank 0)",
+                       "B": B, "H": H, "N": N, "d": d, "causal": False,
+                       "parallelism": f"batch*head shard x{world}, one RCCL all-gather of O (timed beside the compute)"},
+            "pct_mfma_roofline": round(100.0 * flops_total / sec / 1e12 / world / PEAK_BF16_TFLOPS, 2),
+            "roofline": {"bound": "mfma", "kernel": "fwd_slot_kernel<bf16,128>", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops_rank},
+            "cpu_baseline": None,
+            "gather_ms": round(gather_s * 1e3, 3),
+            "gather_bytes_per_rank": int(out.numel() * 4),
+            "fw_with_gather_overlapped_ms": round(over_s * 1e3, 3),
+            "fw_plus_gather_serial_ms": round((sec + gather_s) * 1e3, 3),
+            "value_with_gather_overlapped": round(flops_total / over_s / 1e12, 2),
+        }
+        print(json.dumps(line), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.config == "c4":
+        return main_c4(args)
     import torch
     import torch.distributed as dist
 
@@ -186,20 +361,26 @@ def main():
         if roofline is not None and tf.value > 0:
             roofline["frac_of_sustained_mfma"] = round(roofline["achieved"] / tf.value, 4)
 
-    gather_ms = None
+    # The one all-gather of O the north star describes: reported beside the metric, never inside it.  Every rank takes the same
+    # path (no rank-local try/except: a rank that skipped a collective would leave the others in it).
+    gather_ms = fw_with_gather_ms = None
     if world > 1:
         from flash_attention_minitorch_amd import sharded
-        try:   # reported beside the metric, never inside it: a collective that fails must not cost the bench line
+        sharded.all_gather_bh(out, BH * world)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
             sharded.all_gather_bh(out, BH * world)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                sharded.all_gather_bh(out, BH * world)
-            barrier()
-            gather_ms = (time.perf_counter() - t1) / 3 * 1e3
-        except Exception as e:   # noqa: BLE001
-            print(f"[bench] all-gather timing skipped on rank {rank}: {e!r}", file=sys.stderr, flush=True)
-            gather_ms = None
+        barrier()
+        gather_ms = (time.perf_counter() - t1) / 3 * 1e3
+        # gather-inclusive forward: the gather of piece c hidden under the kernels of piece c+1
+        sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH * world, causal, chunks=4)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH * world, causal, chunks=4)
+        barrier()
+        fw_with_gather_ms = (time.perf_counter() - t1) / 3 * 1e3
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -231,6 +412,10 @@ def main():
                         "single_thread": {"value": round(14.0 * N * N * d * cf / ct1 / 1e12, 5), "unit": "TFLOP/s",
                                           "sample": f"1 head, 1 BLAS thread, {ct1:.1f} s"}}
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = run_extras(torch, device_ops, q, k, v, do, causal)
+
     if rank == 0:
         line = {
             "metric": "attn fw+bw TFLOP/s at (B=8,H=8,N=4096,d=64); % MFMA roofline",
@@ -255,6 +440,9 @@ def main():
             "cpu_baseline": cpu_baseline,
             "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "fw_with_gather_ms": None if fw_with_gather_ms is None else round(fw_with_gather_ms, 3),
+            "vs_vanilla": extras.get("vs_vanilla"),
+            "variants": extras.get("variants"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -8,6 +8,7 @@ Only what the hot path needs lives here:
 * ``cuda_kernel_ops``  host-array operator surface, same names / argument meaning as the reference's
                        ``CudaKernelOps.flash_attn*_fw / _bw`` (``minitorch/cuda_kernel_ops.py:527-677``)
 * ``device_ops``       device-resident (torch-ROCm tensors) entry points + autograd Functions
+* ``modules_transformer``  the in-model caller: MultiHeadAttention data flow on [B][N][H][d], no head-split copies (row f1)
 * ``sharded``          batch*head shard across the GPUs of one node (RCCL all-gather)
 
 The product path never imports ``oracle/`` and has no CPU fallback: if the HIP libraries are missing,

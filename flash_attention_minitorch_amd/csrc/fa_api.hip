@@ -89,20 +89,28 @@ int device_cus() {
   return cus[dev];
 }
 
+// Phased forward.  bf16 rows with fewer than 64 admissible keys need the split-operand build (CARE): whole launches under a key
+// mask, dropout or N < 64; behind a causal launch, query block 0 alone is redone by it (one small workgroup per batch*head).
 template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                    fa::Layout lay, int causal, int variant, float tau, hipStream_t st, int only_qb = -1) {
+  constexpr bool BF = sizeof(T) == 2;
   const int nqb = (N + 127) / 128;
   const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
-  if (lay.drop_thr)   // dropout on P (and the key mask, staged as zeros when absent)
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 2>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, only_qb);
-  else if (lay.kmask)   // additive key mask: staged per tile, enters S^T as the accumulator input
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 1>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, only_qb);
-  else
-    hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, only_qb);
+#define FA_FWD_LAUNCH(FEAT, CARE, BLOCKS, ONLY)                                                                          \
+  hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, FEAT, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q, \
+                     (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, ONLY)
+  if (lay.drop_thr) {   // dropout on P (and the key mask, staged as zeros when absent)
+    FA_FWD_LAUNCH(2, BF, nblk, only_qb);
+  } else if (lay.kmask) {   // additive key mask: staged per tile, enters S^T as the accumulator input
+    FA_FWD_LAUNCH(1, BF, nblk, only_qb);
+  } else if (BF && (N < 64 || only_qb >= 0)) {
+    FA_FWD_LAUNCH(0, BF, nblk, only_qb);
+  } else {
+    FA_FWD_LAUNCH(0, false, nblk, only_qb);
+    if (BF && causal) FA_FWD_LAUNCH(0, BF, 1, 0);   // rows 0..63 see fewer than 64 keys: query block 0 again, split operands
+  }
+#undef FA_FWD_LAUNCH
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
@@ -154,23 +162,44 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
                                                              st);
 }
 
+// bf16 launches whose rows may see fewer than 64 admissible keys everywhere (key mask, dropout, N < 64) run the split-operand
+// build (CARE) in a 4-wave geometry that has the registers for it.  A causal launch runs the requested geometry with the
+// sub-slices of queries 0..63 SKIPPED (thin_mode 1) and then one CARE workgroup per batch*head that handles exactly those and
+// adds its dK, dV (thin_mode 2): the main kernel keeps its registers and its speed.
 template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                 float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
+  constexpr bool BF = sizeof(T) == 2;
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
-  // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key).  (Not instantiated for the 8-wave d = 128
-  // geometry, which dropout calls never take: that build would need 268 registers.)
-  if constexpr (!(sizeof(T) == 2 && D == 128 && NW == 8)) {
-    if (lay.drop_thr) {
+  const int nkb4 = (N + 127) / 128;
+#define FA_CARE_LAUNCH(HD, GRID, THIN)                                                                                        \
+  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 4, 64, 1, HD, 1, BF>), dim3(GRID), dim3(256), 0, st, (const T*)q, (const T*)k, \
+                     (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb4, batch, lay, causal, tau, THIN)
+  if (lay.drop_thr) {   // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key)
+    if constexpr (BF) {
+      FA_CARE_LAUNCH(true, batch * nkb4, 0);
+    } else {
       hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
                          (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
-                         causal, tau);
+                         causal, tau, 0);
+    }
+    FA_HIP_TRY(hipGetLastError());
+    return FA_OK;
+  }
+  if constexpr (BF) {
+    if (lay.kmask || N < 64) {
+      FA_CARE_LAUNCH(false, batch * nkb4, 0);
       FA_HIP_TRY(hipGetLastError());
       return FA_OK;
     }
   }
+  const int thin = (BF && causal) ? 1 : 0;
   hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
-                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau);
+                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau, thin);
+  if constexpr (BF) {
+    if (thin) FA_CARE_LAUNCH(false, batch, 2);
+  }
+#undef FA_CARE_LAUNCH
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
@@ -178,17 +207,23 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
 template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
               float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int only_qb = -1) {
+  constexpr bool BF = sizeof(T) == 2;   // CARE policy as fwd_launch_cfg's
   const int nqb = (N + 127) / 128;
   const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
-  if (lay.drop_thr)
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 2>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb);
-  else if (lay.kmask)
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 1>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb);
-  else
-    hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb);
+#define FA_DQ_LAUNCH(FEAT, CARE, BLOCKS, ONLY)                                                                              \
+  hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, FEAT, 4, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q,   \
+                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, ONLY)
+  if (lay.drop_thr) {
+    FA_DQ_LAUNCH(2, BF, nblk, only_qb);
+  } else if (lay.kmask) {
+    FA_DQ_LAUNCH(1, BF, nblk, only_qb);
+  } else if (BF && (N < 64 || only_qb >= 0)) {
+    FA_DQ_LAUNCH(0, BF, nblk, only_qb);
+  } else {
+    FA_DQ_LAUNCH(0, false, nblk, only_qb);
+    if (BF && causal) FA_DQ_LAUNCH(0, BF, 1, 0);   // rows 0..63 again with split operands
+  }
+#undef FA_DQ_LAUNCH
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
 }
@@ -343,7 +378,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     if constexpr (sizeof(T) == 2 && D == 128) {
       if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr)   // 4 waves x 32 queries, two workgroups per CU
+      else if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr || N < 64)   // 4 waves x 32 queries, two workgroups per CU
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
         const int nqb = (N + 255) / 256;

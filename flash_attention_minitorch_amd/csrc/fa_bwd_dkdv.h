@@ -45,11 +45,14 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 // the dK^T, dV^T accumulators of its KPW keys in registers while the workgroup sweeps 32-row query slices
 // (Q, dO tiles + their nlc, delta staged in LDS, double buffered).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false, int MINW = 1>
+// CARE: the build whose per-sub-slice path splits P and dS into two bf16 fragments on rows with few admissible keys (bf16 only).
+// thin_mode (causal launches): 1 = this launch SKIPS the sub-slices of queries 0..63 (the rows with fewer than 64 keys); 2 = this
+// launch handles ONLY those (key block 0, one workgroup per batch*head, CARE build) and ADDS its dK, dV to what mode 1 stored.
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false, int MINW = 1, bool CARE = false>
 __global__ void __launch_bounds__(NW * 64, MINW)   // MINW: minimum waves per SIMD the register allocation must allow
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
-                float* __restrict__ dv, int N, int nkb, int BH, Layout lay, int causal, float tau) {
+                float* __restrict__ dv, int N, int nkb, int BH, Layout lay, int causal, float tau, int thin_mode = 0) {
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = NW * KPW, NT = NW * 64, NSUB = QS / 32;
@@ -61,7 +64,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh, kb;
-  map_block(blockIdx.x, BH, nkb, bh, kb);
+  map_block(blockIdx.x, BH, thin_mode == 2 ? 1 : nkb, bh, kb);
   const int kb0 = kb * BK, kw0 = kb0 + w * KPW;
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
@@ -102,7 +105,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
-  const int nqi = (N + QS - 1) / QS;
+  const int nqi = thin_mode == 2 ? 1 : (N + QS - 1) / QS;   // (mode 2: queries 0..63 lie in the first stage)
   const int qi_begin = causal ? (kb0 / QS) : 0;  // query slices entirely above the key block are fully masked
   // Stage copies of Q and dO.  bf16, d >= 64: LDS-DMA, 1 KiB pieces (half an 8-row group at d = 128), the image's chunk swizzle
   // applied to each lane's source address; wave w moves pieces w, w + NW, ... (same swizzle parity, one lane offset) -- no
@@ -171,8 +174,9 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   // Stages whose query rows may see fewer than 64 admissible keys (the first rows under the causal mask, N < 64, a key mask or
   // dropout thinning the row) take the per-sub-slice path, where P and dS enter the dV / dK products as two bf16 fragments each
   // (Atom::pack_lo): on such rows their 2^-9 rounding is not averaged out (bf16 only; wave-uniform).
-  const bool thin = A::SPLITS && (HD || lay.kmask != nullptr);
-  auto careful_stage = [&](int qi_) { return A::SPLITS && (thin || (causal ? qi_ * QS < 64 : N < 64)); };
+  const bool thin = CARE && A::SPLITS && (HD || lay.kmask != nullptr);
+  // (causal: the stage of queries 0..63 always takes the per-sub-slice path, which is also where thin_mode skips / selects)
+  auto careful_stage = [&](int qi_) { return A::SPLITS && (thin || (causal ? qi_ * QS < 64 : (CARE && N < 64))); };
   auto slice = [&](auto par, int qi) {
     constexpr int PAR = decltype(par)::value;
     const bool more = qi + 1 < nqi;
@@ -406,7 +410,8 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
       const int qi0 = qi * QS + 32 * sub;
-      const bool active = (kw0 < N) && (qi0 < N) && (!causal || qi0 + 31 >= kw0);  // wave-uniform
+      const bool active = (kw0 < N) && (qi0 < N) && (!causal || qi0 + 31 >= kw0) &&
+                          !(thin_mode == 1 && qi0 < 64) && !(thin_mode == 2 && qi0 >= 64);  // wave-uniform
       if (active) {
         // register i of lane half h is query qi0 + acc_row(i, h): its nlc / -delta come from LDS (broadcast reads);
         // -delta enters the dP tile as the accumulator input of its first MFMA
@@ -485,38 +490,44 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           t3 = stamp();
           ph[2] += t3 - t2;
         }
+        if (!(CARE && (thin || (A::SPLITS && (causal ? qi0 < 64 : N < 64))))) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+          for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
-            const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-              A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
-              A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
-            }
-          }
-        if (thin || (A::SPLITS && (causal ? qi0 < 64 : N < 64))) {   // rows with few admissible keys: what the bf16 rounding of P, dS dropped
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            frag pl[KT], dl[KT];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-              pl[kt] = A::pack_lo(s[kt], s2, pf[kt][s2]);
-              dl[kt] = A::pack_lo(dp[kt], s2, dsf[kt][s2]);
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
+            for (int s2 = 0; s2 < 2; ++s2) {
               const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
               const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
 #pragma unroll
               for (int kt = 0; kt < KT; ++kt) {
-                A::mma(acc_dv[dt][kt], adoT, pl[kt]);
-                A::mma(acc_dk[dt][kt], aqT, dl[kt]);
+                A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
+                A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
               }
             }
-          }
+        } else {
+          // rows with few admissible keys: both products also take what the bf16 rounding of P, dS dropped (the residual fragments
+          // are formed first, so the fp32 tiles are dead before the MFMAs; each transposed fragment feeds both)
+          frag pl[KT][2], dl[KT][2];
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              pl[kt][s2] = A::pack_lo(s[kt], s2, pf[kt][s2]);
+              dl[kt][s2] = A::pack_lo(dp[kt], s2, dsf[kt][s2]);
+            }
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
+              const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
+#pragma unroll
+              for (int kt = 0; kt < KT; ++kt) {
+                A::mma(acc_dv[dt][kt], adoT, pf[kt][s2]);
+                A::mma(acc_dv[dt][kt], adoT, pl[kt][s2]);
+                A::mma(acc_dk[dt][kt], aqT, dsf[kt][s2]);
+                A::mma(acc_dk[dt][kt], aqT, dl[kt][s2]);
+              }
+            }
         }
         if constexpr (DIAG) { t0 = stamp(); ph[3] += t0 - t3; }
       }
@@ -557,8 +568,14 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
                      acc_dk[dt][kt][4 * g + 3] * tau};
           f32x4 b = {acc_dv[dt][kt][4 * g], acc_dv[dt][kt][4 * g + 1], acc_dv[dt][kt][4 * g + 2],
                      acc_dv[dt][kt][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h) = a;
-          *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h) = b;
+          f32x4* pk = reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h);
+          f32x4* pv = reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h);
+          if (thin_mode == 2) {   // the rows' other contributions were stored by the launch before this one (same stream)
+            a += *pk;
+            b += *pv;
+          }
+          *pk = a;
+          *pv = b;
         }
     }
   }

@@ -9,7 +9,7 @@ namespace fa {
 // Backward dQ: same shape as the forward (NWQ waves x 32 query rows, K/V tiles of BN keys through LDS).  NWQ = 4 by
 // default; the bf16 d = 128 launch uses 8 (one workgroup per CU sharing each staged tile between twice the waves).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4>
+template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4, bool CARE = false>   // CARE: as fwd_kernel's
 __global__ void __launch_bounds__(64 * NWQ)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
@@ -34,7 +34,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   const int qb = only_qb >= 0 ? only_qb : (causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk);
   const int q0 = qb * (32 * NWQ) + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
-  const bool careful = A::SPLITS && (HM || HD || (causal ? q0 < 64 : N < 64));   // wave-uniform: see fwd_kernel
+  const bool careful = CARE && A::SPLITS && (HM || HD || (causal ? q0 < 64 : N < 64));   // wave-uniform: see fwd_kernel
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
@@ -156,23 +156,31 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
         dsf[kt][0] = A::pack(dp[kt], 0);
         dsf[kt][1] = A::pack(dp[kt], 1);
       }
+      if (!careful) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+          for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-            A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dsf[kt][s2]);
-      if (careful) {   // rows with few admissible keys: K^T dS^T once more with what the bf16 rounding of dS dropped
+            for (int s2 = 0; s2 < 2; ++s2)
+              A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dsf[kt][s2]);
+      } else {   // rows with few admissible keys: K^T dS^T also takes what the bf16 rounding of dS dropped
+        frag dl[KT][2];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT; ++kt) {
+          dl[kt][0] = A::pack_lo(dp[kt], 0, dsf[kt][0]);
+          dl[kt][1] = A::pack_lo(dp[kt], 1, dsf[kt][1]);
+        }
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const frag dl = A::pack_lo(dp[kt], s2, dsf[kt][s2]);
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-              A::mma(acc[dt], A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt), dl);
-          }
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const frag kt_ = A::template tr_frag<D>(tk, ta, 32 * kt + 16 * s2, dt);
+              A::mma(acc[dt], kt_, dsf[kt][s2]);
+              A::mma(acc[dt], kt_, dl[kt][s2]);
+            }
       }
     }
     if (more) {

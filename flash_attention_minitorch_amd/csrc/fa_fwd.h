@@ -17,7 +17,9 @@ namespace fa {
 // ---------------------------------------------------------------------------------------------
 constexpr float MAX_DEFER_SUM = 64.0f;   // 2^6: bound on a lane's partial row sum (hence on every P) in the steady state
 
-template <typename T, int D, int BN, int WPE, int FEAT = 0>
+// CARE: the build with the split-operand path for rows with few admissible keys (see `careful` below); the launcher runs it for
+// whole launches that need it everywhere (key mask, dropout, N < 64) and, behind a causal launch, for query block 0 alone.
+template <typename T, int D, int BN, int WPE, int FEAT = 0, bool CARE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
            float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, Layout lay, int causal,
@@ -47,7 +49,7 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   const bool qvalid = qrow < N;
   // wave-uniform: this wave's rows may see fewer than 64 admissible keys (or a mask / dropout thins them): operands that the
   // second product takes in bf16 are then split into two fragments (Atom::pack_lo).  bf16 only: the fp32 atom is exact.
-  const bool careful = A::SPLITS && (HM || HD || (causal ? q0 < 64 : N < 64));
+  const bool careful = CARE && A::SPLITS && (HM || HD || (causal ? q0 < 64 : N < 64));
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
@@ -198,23 +200,31 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
         pf[kt][0] = A::pack(s[kt], 0);
         pf[kt][1] = A::pack(s[kt], 1);
       }
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pf[kt][s2]);
-      if (careful) {   // rows with few admissible keys: P.V once more with what the bf16 rounding of P dropped
+      if (!careful) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const frag pl = A::pack_lo(s[kt], s2, pf[kt][s2]);
+          for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-              A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pl);
-          }
+              A::mma(acc_o[dt], A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt), pf[kt][s2]);
+      } else {   // rows with few admissible keys: P.V also takes what the bf16 rounding of P dropped (each V fragment feeds both)
+        frag pl[KT][2];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          pl[kt][0] = A::pack_lo(s[kt], 0, pf[kt][0]);
+          pl[kt][1] = A::pack_lo(s[kt], 1, pf[kt][1]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const frag vt = A::template tr_frag<D>(tv, ta, 32 * kt + 16 * s2, dt);
+              A::mma(acc_o[dt], vt, pf[kt][s2]);
+              A::mma(acc_o[dt], vt, pl[kt][s2]);
+            }
       }
     }
     if (more) {

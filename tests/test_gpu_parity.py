@@ -446,6 +446,68 @@ def test_ragged_tail_with_very_negative_logsumexp(dev, dtype, d, N):
         assert maxabs(g, ref[nm]) < tol * scale, (nm, maxabs(g, ref[nm]), scale)
 
 
+# ---------------------------------------------------------------- row f3: flash vs vanilla attention ON THE GPU
+def _vanilla():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import vanilla_gpu
+    return vanilla_gpu
+
+
+@pytest.mark.parametrize("N", [128, 1024])
+@pytest.mark.parametrize("fw,bw", [("flash_attn_fw", "flash_attn_bw"), ("flash_attn_causal_fw", "flash_attn_causal_bw"),
+                                   ("flash_attn2_fw", "flash_attn2_bw")])
+def test_flash_matches_gpu_vanilla_attention_reference_shapes(ops, fw, bw, N):
+    """The reference pins flash == vanilla on the GPU: kernel_tests/test_flashattn_fw.py:23-156 (B=1, H=8, d=64, causal_mask=True,
+    atol = rtol = 1e-3) and test_flashattn_bw.py:19-210 (out_grad = ones, atol 1e-2, rtol 1e-3), for its three operator variants.
+    Vanilla here: torch-ROCm fp32 matmul + softmax with the reference's -FLT_MAX causal mask (tools/vanilla_gpu.py)."""
+    import torch
+    vg = _vanilla()
+    rng = np.random.default_rng(2300 + N)
+    shp = (1, 8, N, 64)
+    q, k, v = (rand_u(rng, shp) for _ in range(3))
+    do = np.ones(shp, np.float32)
+    o, l, m = getattr(ops, fw)(q, k, v, True)
+    dq, dk, dv, _ = getattr(ops, bw)(q, k, v, o, do, l, m, True)
+    ro, rdq, rdk, rdv = (to_np(t) for t in vg.vanilla_fw_bw(*(torch.from_numpy(a).cuda() for a in (q, k, v, do)), True))
+    np.testing.assert_allclose(o, ro, atol=1e-3, rtol=1e-3)
+    for got, ref in ((dq, rdq), (dk, rdk), (dv, rdv)):
+        np.testing.assert_allclose(got, ref, atol=1e-2, rtol=1e-3)
+    # (and far inside those bounds: both sides are fp32)
+    assert maxabs(o, ro) < TOL32 and max(maxabs(dq, rdq), maxabs(dk, rdk), maxabs(dv, rdv)) < 2e-4
+
+
+def test_flash_matches_gpu_vanilla_attention_comb_shape(ops):
+    """kernel_tests/test_flashattn_comb.py:86-90: B=128, H=8, N=40, d=32, non-causal, out_grad = ones."""
+    import torch
+    vg = _vanilla()
+    rng = np.random.default_rng(2386)
+    shp = (128, 8, 40, 32)
+    q, k, v = (rand_u(rng, shp) for _ in range(3))
+    do = np.ones(shp, np.float32)
+    o, l, m = ops.flash_attn_fw(q, k, v, False)
+    dq, dk, dv, _ = ops.flash_attn_bw(q, k, v, o, do, l, m, False)
+    ro, rdq, rdk, rdv = (to_np(t) for t in vg.vanilla_fw_bw(*(torch.from_numpy(a).cuda() for a in (q, k, v, do)), False))
+    np.testing.assert_allclose(o, ro, atol=1e-3, rtol=1e-3)
+    for got, ref in ((dq, rdq), (dk, rdk), (dv, rdv)):
+        np.testing.assert_allclose(got, ref, atol=1e-2, rtol=1e-3)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_device_bf16_flash_matches_gpu_vanilla_attention(dev, causal):
+    """The device-resident bf16 path against the same GPU vanilla attention evaluated in fp32 on the bf16-rounded inputs."""
+    import torch
+    vg = _vanilla()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda: ((torch.rand((16, 1024, 64), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    o, l, _ = dev.flash_attn_fwd(q, k, v, causal)
+    dq, dk, dv = dev.flash_attn_bwd(q, k, v, o, do, l, None, causal)
+    ro, rdq, rdk, rdv = vg.vanilla_fw_bw(q.float(), k.float(), v.float(), do.float(), causal)
+    for nm, a, b in (("o", o, ro), ("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv)):
+        assert float((a - b).abs().max()) < TOLBF, nm
+
+
 def test_random_shapes_bf16(dev):
     """Seeded sweep over sequence lengths that straddle every structural size of the bf16 kernels (32-key sub-tiles, 64 / 128
     key stages, 128 / 256 query workgroups, 3 / 4 slot rings), head dims, causal flag and batch*head counts that do and do
@@ -625,6 +687,15 @@ def test_bnhd_layout_matches_permuted_copy(dev, dtype, causal, N):
             assert torch.equal(m, m_r)
         for a, b in zip((dq, dk, dv), g_r):
             assert torch.equal(perm(a), b)
+        # ... and against the ORACLE directly (a HIP-vs-HIP comparison alone is not evidence)
+        f = lambda t: to_np(perm(t).float())
+        ref = oracle_heads(f(q).reshape(B * H, N, d), f(k).reshape(B * H, N, d), f(v).reshape(B * H, N, d),
+                           f(do).reshape(B * H, N, d), causal, range(B * H))
+        tol = TOLBF if dtype == "bf16" else TOL32
+        L = to_np(l) if variant == _lib.FA_VARIANT_FA2 else to_np(m) + np.log(to_np(l))
+        assert maxabs(f(o).reshape(B * H, N, d), ref["o"]) < tol and maxabs(L.reshape(B * H, N), ref["L"]) < tol
+        for nm, a in (("dq", dq), ("dk", dk), ("dv", dv)):
+            assert maxabs(f(a).reshape(B * H, N, d), ref[nm]) < tol, nm
 
 
 def test_autograd_functions_follow_reference_contract(dev):

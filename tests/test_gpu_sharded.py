@@ -1,0 +1,80 @@
+"""The N > 1 path with the DEFAULT compute function (the HIP kernels) on one GPU: sharded_flash_attn2_fwd / _bwd /
+_fwd_overlapped in a single-process, world-size-1 RCCL group on cuda:0, at the shape one rank of BASELINE.json configs[4]
+(B=128, H=16, N=4096, d=128 forward over 8 GPUs: 256 (batch, head) pairs per rank) holds.  The gloo tests
+(tests/test_sharded_cpu.py) cover the partitioning with world sizes 2 and 3; this covers what they cannot: the real kernels
+behind the collective calls, and the overlapped gather's chunking on the real device."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+from gpu_util import maxabs, oracle_heads, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def group():
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _mk(bh, n, d, seed):
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    return [((torch.rand((bh, n, d), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16) for _ in range(4)]
+
+
+def test_sharded_default_compute_small_slice_against_oracle(group):
+    """A c4-slice-shaped input with few heads (N = 4096, d = 128, bf16): forward, overlapped forward and backward through
+    sharded.py's default compute functions, against the fp64 oracle."""
+    import torch
+    from flash_attention_minitorch_amd import sharded
+    BH, N, d = 4, 4096, 128
+    q, k, v, do = _mk(BH, N, d, 11)
+    o, L = sharded.sharded_flash_attn2_fwd(q, k, v, BH)
+    o2, L2 = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH, chunks=2)
+    o_loc, L_loc = sharded.sharded_flash_attn2_fwd(q, k, v, BH, gather=False)
+    dq, dk, dv = sharded.sharded_flash_attn2_bwd(q, k, v, o_loc, do, L_loc, BH)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2) and torch.equal(L, L2) and torch.equal(o, o_loc)
+    heads = [0, 3]
+    arrs = [to_np(t.float())[heads] for t in (q, k, v, do)]
+    ref = oracle_heads(*arrs, False, range(len(heads)))
+    assert maxabs(to_np(o)[heads], ref["o"]) < 1e-3 and maxabs(to_np(L)[heads], ref["L"]) < 1e-3
+    for nm, g in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert maxabs(to_np(g)[heads], ref[nm]) < 1e-3, nm
+
+
+def test_sharded_default_compute_full_c4_rank_slice_properties(group):
+    """The full per-rank slice of configs[4] (BH = 256, N = 4096, d = 128, bf16 forward): size-independent properties.
+    V = 1 gives O = 1 exactly-ish; the overlapped gather (4 chunks) returns the one-shot gather's tensors bit for bit;
+    sampled heads agree with the oracle."""
+    import torch
+    from flash_attention_minitorch_amd import sharded
+    BH, N, d = 256, 4096, 128
+    q, k, v, _ = _mk(BH, N, d, 12)
+    o, L = sharded.sharded_flash_attn2_fwd(q, k, v, BH)
+    o4, L4 = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH, chunks=4)
+    torch.cuda.synchronize()
+    assert o.shape == (BH, N, d) and L.shape == (BH, N)
+    assert torch.equal(o, o4) and torch.equal(L, L4)
+    ones = torch.ones_like(v)
+    o1, _ = sharded.sharded_flash_attn2_fwd(q, k, ones, BH)
+    assert float((o1 - 1.0).abs().max()) < 1e-3
+    heads = [5, 250]
+    arrs = [to_np(t.float())[heads] for t in (q, k, v)]
+    ro, rL, _, _ = oracle.dense_attention_fw(*arrs)
+    assert maxabs(to_np(o)[heads], ro) < 1e-3 and maxabs(to_np(L)[heads], rL) < 1e-3

@@ -1,0 +1,42 @@
+"""GPU "vanilla" (materialised-S) attention in plain torch-ROCm: the comparator of the reference's own flash-vs-vanilla tests and
+timing harness (softmax((q @ kT) / sqrt(d) + mask) @ v with mask = -FLT_MAX * triu(ones, 1):
+kernel_tests/test_flashattn_fw.py:18-20,64-72, test_flashattn_time.py:38-62, minitorch/modules_transfomer.py:123-127).
+Measurement / test infrastructure only: nothing in the product path imports it."""
+import numpy as np
+import torch
+
+
+def causal_mask(n, device, dtype=torch.float32):
+    # kernel_tests/test_flashattn_fw.py:18-20: -finfo(float32).max on the strict upper triangle
+    return torch.triu(torch.full((n, n), -float(np.finfo(np.float32).max), device=device, dtype=dtype), 1)
+
+
+def vanilla_attention(q, k, v, causal, softmax_dtype=torch.float32):
+    """q, k, v: (..., N, d).  Scores and softmax in ``softmax_dtype``; the two matmuls in the inputs' dtype."""
+    n, d = q.shape[-2], q.shape[-1]
+    s = torch.matmul(q, k.transpose(-1, -2)).to(softmax_dtype) * (d ** -0.5)
+    if causal:
+        s = s + causal_mask(n, q.device, softmax_dtype)
+    p = torch.softmax(s, dim=-1)
+    return torch.matmul(p.to(v.dtype), v)
+
+
+def vanilla_fw_bw(q, k, v, do, causal):
+    """Returns (o, dq, dk, dv) by autograd through the vanilla forward."""
+    qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    o = vanilla_attention(qq, kk, vv, causal)
+    o.backward(do.to(o.dtype))
+    return o.detach(), qq.grad, kk.grad, vv.grad
+
+
+def time_ms(fn, iters=5, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
