@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <stdio.h>
@@ -464,17 +465,27 @@ int check_common(int batch, int N, int d, int variant, int dtype) {
 std::mutex g_pool_mu;
 void* g_pool = nullptr;
 size_t g_pool_bytes = 0;
+int g_pool_dev = -1;   // the arena belongs to the device that was current when it was allocated
 
 hipError_t pool_reserve(size_t bytes) {
-  if (bytes <= g_pool_bytes) return hipSuccess;
-  if (g_pool) {
-    hipError_t e = hipFree(g_pool);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (g_pool && dev == g_pool_dev && bytes <= g_pool_bytes) return hipSuccess;
+  if (g_pool) {   // grow, or the caller moved to another device: the old arena is released on ITS device
+    int cur = dev;
+    if (g_pool_dev != dev) hipSetDevice(g_pool_dev);
+    e = hipFree(g_pool);
+    if (g_pool_dev != cur) hipSetDevice(cur);
     g_pool = nullptr;
     g_pool_bytes = 0;
     if (e != hipSuccess) return e;
   }
-  hipError_t e = hipMalloc(&g_pool, bytes);
-  if (e == hipSuccess) g_pool_bytes = bytes;
+  e = hipMalloc(&g_pool, bytes);
+  if (e == hipSuccess) {
+    g_pool_bytes = bytes;
+    g_pool_dev = dev;
+  }
   return e;
 }
 
@@ -509,6 +520,60 @@ void d2h_rows(float* dst, const float* src, size_t rows, int d, int dp, hipStrea
     FA_HOST_TRY(hipMemcpy2DAsync(dst, d * sizeof(float), src, dp * sizeof(float), d * sizeof(float), rows,
                                  hipMemcpyDeviceToHost, st));
   }
+}
+
+
+// ---- host-pointer path as a pipeline --------------------------------------------------------
+// The reference uploads everything, runs one kernel, downloads everything (src/flash_attn_fw.cu:314-357).  Here the call is
+// cut into chunks of (batch*head) rows: H2D of chunk c+1, the kernels of chunk c and D2H of chunk c-1 run on three streams
+// (both DMA directions and the compute overlap), and the caller's arrays are pinned in place for the duration of the call
+// (hipHostRegister: no staging copy by the CPU; a range that cannot be pinned is copied pageable, same results).
+struct Pinned {
+  void* p = nullptr;
+  Pinned(const void* ptr, size_t bytes) {
+    if (bytes >= (1u << 20) && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+    else (void)hipGetLastError();
+  }
+  ~Pinned() { if (p) (void)hipHostUnregister(p); }
+  Pinned(const Pinned&) = delete;
+  Pinned& operator=(const Pinned&) = delete;
+};
+struct HostPipe {
+  hipStream_t up = nullptr, down = nullptr;
+  std::vector<hipEvent_t> ev;
+  hipEvent_t event(size_t i) {
+    while (ev.size() <= i) {
+      hipEvent_t e;
+      FA_HOST_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev.push_back(e);
+    }
+    return ev[i];
+  }
+  void init() {
+    if (!up) FA_HOST_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    if (!down) FA_HOST_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+  }
+};
+HostPipe g_pipe;   // guarded by g_pool_mu, like the arena
+// FA_MI355X_HOST_TIMING=1: one stderr line per host-pointer call with the time spent pinning, in the pipeline, and unpinning
+struct HostTimer {
+  const char* what;
+  bool on;
+  std::chrono::steady_clock::time_point t0, t1, t2;
+  explicit HostTimer(const char* w) : what(w), on(getenv("FA_MI355X_HOST_TIMING") != nullptr) { t0 = t1 = t2 = std::chrono::steady_clock::now(); }
+  void pinned() { t1 = std::chrono::steady_clock::now(); }
+  void piped() { t2 = std::chrono::steady_clock::now(); }
+  ~HostTimer() {
+    if (!on) return;
+    const auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[fa_mi355x host %s] pin %.2f ms, pipeline %.2f ms, unpin %.2f ms\n", what, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+  }
+};
+inline int host_chunks(int batch, size_t bytes_per_bh) {
+  // ~32 MiB of input per chunk and tensor, at most 8 chunks: enough to hide the tails, few enough to keep the launches cheap
+  const size_t want = (bytes_per_bh * (size_t)batch + (32u << 20) - 1) / (32u << 20);
+  return (int)std::max<size_t>(1, std::min<size_t>({want, (size_t)8, (size_t)batch}));
 }
 
 }  // namespace
@@ -786,6 +851,7 @@ void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* 
   const size_t tb = align256(rows * dp * sizeof(float)), rb = align256(rows * sizeof(float));
   std::lock_guard<std::mutex> lock(g_pool_mu);
   FA_HOST_TRY(pool_reserve(4 * tb + 2 * rb));
+  g_pipe.init();
   char* p = (char*)g_pool;
   float* dq_ = (float*)p;
   float* dk_ = (float*)(p + tb);
@@ -793,18 +859,36 @@ void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* 
   float* do_ = (float*)(p + 3 * tb);
   float* dl_ = (float*)(p + 4 * tb);
   float* dm_ = (float*)(p + 4 * tb + rb);
-  h2d_rows(dq_, q, rows, d, dp, st);
-  h2d_rows(dk_, k, rows, d, dp, st);
-  h2d_rows(dv_, v, rows, d, dp, st);
-  if (fwd_dispatch(dq_, dk_, dv_, do_, dl_, dm_, batch, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0, variant,
-                   FA_DTYPE_F32, st))
-    die(g_err, hipSuccess);
-  d2h_rows(out, do_, rows, d, dp, st);
-  FA_HOST_TRY(hipMemcpyAsync(l, dl_, rows * sizeof(float), hipMemcpyDeviceToHost, st));
-  // FA-2 never writes m (src/flash_attn2_fw.cu:279-294): the caller's m comes back unchanged.
-  if (variant == FA_VARIANT_FA1) FA_HOST_TRY(hipMemcpyAsync(m, dm_, rows * sizeof(float), hipMemcpyDeviceToHost, st));
+  const size_t tbytes = rows * d * sizeof(float), rbytes = rows * sizeof(float);
+  HostTimer tm("fw");
+  Pinned pq(q, tbytes), pk(k, tbytes), pv(v, tbytes), po(out, tbytes), pl(l, rbytes), pm(m, variant == FA_VARIANT_FA1 ? rbytes : 0);
+  tm.pinned();
+  const int nch = host_chunks(batch, (size_t)N * d * sizeof(float));
+  const int cb = (batch + nch - 1) / nch;
+  FA_HOST_TRY(hipStreamSynchronize(st));   // the arena may still be in use by work the caller queued on this stream
+  for (int c = 0, b0 = 0; b0 < batch; ++c, b0 += cb) {
+    const int nb = std::min(cb, batch - b0);
+    const size_t r0 = (size_t)b0 * N, nr = (size_t)nb * N;
+    h2d_rows(dq_ + r0 * dp, q + r0 * d, nr, d, dp, g_pipe.up);
+    h2d_rows(dk_ + r0 * dp, k + r0 * d, nr, d, dp, g_pipe.up);
+    h2d_rows(dv_ + r0 * dp, v + r0 * d, nr, d, dp, g_pipe.up);
+    FA_HOST_TRY(hipEventRecord(g_pipe.event(2 * c), g_pipe.up));
+    FA_HOST_TRY(hipStreamWaitEvent(st, g_pipe.event(2 * c), 0));
+    if (fwd_dispatch(dq_ + r0 * dp, dk_ + r0 * dp, dv_ + r0 * dp, do_ + r0 * dp, dl_ + r0, dm_ + r0, nb, N, d, dp, bhnd(N, dp),
+                     causal_mask ? 1 : 0, variant, FA_DTYPE_F32, st))
+      die(g_err, hipSuccess);
+    FA_HOST_TRY(hipEventRecord(g_pipe.event(2 * c + 1), st));
+    FA_HOST_TRY(hipStreamWaitEvent(g_pipe.down, g_pipe.event(2 * c + 1), 0));
+    d2h_rows(out + r0 * d, do_ + r0 * dp, nr, d, dp, g_pipe.down);
+    FA_HOST_TRY(hipMemcpyAsync(l + r0, dl_ + r0, nr * sizeof(float), hipMemcpyDeviceToHost, g_pipe.down));
+    // FA-2 never writes m (src/flash_attn2_fw.cu:279-294): the caller's m comes back unchanged.
+    if (variant == FA_VARIANT_FA1)
+      FA_HOST_TRY(hipMemcpyAsync(m + r0, dm_ + r0, nr * sizeof(float), hipMemcpyDeviceToHost, g_pipe.down));
+  }
+  FA_HOST_TRY(hipStreamSynchronize(g_pipe.down));
   FA_HOST_TRY(hipStreamSynchronize(st));
   FA_HOST_TRY(hipGetLastError());
+  tm.piped();
 }
 
 void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* out, float* out_grad, float* q_grad,
@@ -820,6 +904,7 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
   const size_t tb = align256(rows * dp * sizeof(float)), rb = align256(rows * sizeof(float));
   std::lock_guard<std::mutex> lock(g_pool_mu);
   FA_HOST_TRY(pool_reserve(8 * tb + 4 * rb));
+  g_pipe.init();
   char* p = (char*)g_pool;
   float* bq = (float*)p;
   float* bk = (float*)(p + tb);
@@ -831,22 +916,42 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
   float* bdv = (float*)(p + 7 * tb);
   float* bl = (float*)(p + 8 * tb);
   float* bm = (float*)(p + 8 * tb + rb);
-  float* ws = (float*)(p + 8 * tb + 2 * rb);
-  h2d_rows(bq, q, rows, d, dp, st);
-  h2d_rows(bk, k, rows, d, dp, st);
-  h2d_rows(bv, v, rows, d, dp, st);
-  h2d_rows(bo, out, rows, d, dp, st);
-  h2d_rows(bdo, out_grad, rows, d, dp, st);
-  FA_HOST_TRY(hipMemcpyAsync(bl, l, rows * sizeof(float), hipMemcpyHostToDevice, st));
-  FA_HOST_TRY(hipMemcpyAsync(bm, m, rows * sizeof(float), hipMemcpyHostToDevice, st));
-  if (bwd_dispatch(bq, bk, bv, bo, bdo, bdq, bdk, bdv, bl, bm, ws, batch, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0,
-                   variant, FA_DTYPE_F32, FA_BWD_STAGE_ALL, st))
-    die(g_err, hipSuccess);
-  d2h_rows(q_grad, bdq, rows, d, dp, st);
-  d2h_rows(k_grad, bdk, rows, d, dp, st);
-  d2h_rows(v_grad, bdv, rows, d, dp, st);
+  float* ws = (float*)(p + 8 * tb + 2 * rb);   // 2 * rows floats: -L/tau and -delta of every chunk at its own rows
+  const size_t tbytes = rows * d * sizeof(float), rbytes = rows * sizeof(float);
+  HostTimer tm("bw");
+  Pinned pq(q, tbytes), pk(k, tbytes), pv(v, tbytes), po(out, tbytes), pdo(out_grad, tbytes), pl(l, rbytes), pm(m, rbytes),
+      pgq(q_grad, tbytes), pgk(k_grad, tbytes), pgv(v_grad, tbytes);
+  tm.pinned();
+  const int nch = host_chunks(batch, (size_t)N * d * sizeof(float));
+  const int cb = (batch + nch - 1) / nch;
+  FA_HOST_TRY(hipStreamSynchronize(st));
+  for (int c = 0, b0 = 0; b0 < batch; ++c, b0 += cb) {
+    const int nb = std::min(cb, batch - b0);
+    const size_t r0 = (size_t)b0 * N, nr = (size_t)nb * N;
+    h2d_rows(bq + r0 * dp, q + r0 * d, nr, d, dp, g_pipe.up);
+    h2d_rows(bk + r0 * dp, k + r0 * d, nr, d, dp, g_pipe.up);
+    h2d_rows(bv + r0 * dp, v + r0 * d, nr, d, dp, g_pipe.up);
+    h2d_rows(bo + r0 * dp, out + r0 * d, nr, d, dp, g_pipe.up);
+    h2d_rows(bdo + r0 * dp, out_grad + r0 * d, nr, d, dp, g_pipe.up);
+    FA_HOST_TRY(hipMemcpyAsync(bl + r0, l + r0, nr * sizeof(float), hipMemcpyHostToDevice, g_pipe.up));
+    FA_HOST_TRY(hipMemcpyAsync(bm + r0, m + r0, nr * sizeof(float), hipMemcpyHostToDevice, g_pipe.up));
+    FA_HOST_TRY(hipEventRecord(g_pipe.event(2 * c), g_pipe.up));
+    FA_HOST_TRY(hipStreamWaitEvent(st, g_pipe.event(2 * c), 0));
+    // the chunk's two row-constant vectors sit at ws + 2 * r0 (the kernels take ws and ws + rows of THEIR launch)
+    if (bwd_dispatch(bq + r0 * dp, bk + r0 * dp, bv + r0 * dp, bo + r0 * dp, bdo + r0 * dp, bdq + r0 * dp, bdk + r0 * dp,
+                     bdv + r0 * dp, bl + r0, bm + r0, ws + 2 * r0, nb, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0, variant,
+                     FA_DTYPE_F32, FA_BWD_STAGE_ALL, st))
+      die(g_err, hipSuccess);
+    FA_HOST_TRY(hipEventRecord(g_pipe.event(2 * c + 1), st));
+    FA_HOST_TRY(hipStreamWaitEvent(g_pipe.down, g_pipe.event(2 * c + 1), 0));
+    d2h_rows(q_grad + r0 * d, bdq + r0 * dp, nr, d, dp, g_pipe.down);
+    d2h_rows(k_grad + r0 * d, bdk + r0 * dp, nr, d, dp, g_pipe.down);
+    d2h_rows(v_grad + r0 * d, bdv + r0 * dp, nr, d, dp, g_pipe.down);
+  }
+  FA_HOST_TRY(hipStreamSynchronize(g_pipe.down));
   FA_HOST_TRY(hipStreamSynchronize(st));
   FA_HOST_TRY(hipGetLastError());
+  tm.piped();
 }
 
 int fa_mi355x_probe(const void* tile, const void* b, float* row_out, float* tr_out, float* mma_out, float* swap_out,

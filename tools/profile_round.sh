@@ -10,8 +10,8 @@ OUT="$R/gpurun_out"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$R"
-B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-}"
-S="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-breakdown ${BENCH_ARGS:-}"
+B="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"
+S="python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-breakdown ${BENCH_ARGS:-}"
 run() { echo "=== $*"; timeout -k 10 300 "$@" > "$OUT/${TAG}_last.log" 2>&1; rc=$?; tail -n 3 "$OUT/${TAG}_last.log"; echo "=== exit $rc"; return $rc; }
 run rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_trace" -o t -- $B || exit 1
 grep '"metric"' "$OUT/${TAG}_last.log" > "$OUT/${TAG}_bench_under_trace.json" || true
