@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--config", choices=["metric", "c4"], default="metric",
                     help="metric: BASELINE.json's headline shape (default); c4: configs[4], forward sharded over the ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip vs_vanilla / variants (rank 0, --gpus 1 only)")
+    ap.add_argument("--opts", type=str, default="", help="comma-separated per-call kernel options (fa_mi355x_*_ex), A/B runs only")
     ap.add_argument("--phased", action="store_true",
                     help="profiling A/B only: run the phased (round-1 v5) kernels instead of the MFMA-slot ones")
     return ap.parse_args()
@@ -257,6 +258,8 @@ def main():
 
     from flash_attention_minitorch_amd import device_ops
     OPTS = device_ops.OPTS_PHASED if args.phased else None   # per-call kernel options (no process-wide state)
+    if args.opts:
+        OPTS = tuple(int(x) for x in args.opts.split(","))
 
     B, H, N, d = args.batch, args.heads, args.seqlen, args.headdim
     BH = B * H
@@ -346,6 +349,8 @@ def main():
                 traffic = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                    "this bench command (gfx950 wide-read correction applied), not a counter read in this run",
                     "avg_launch_ms": round(dur_ms, 4), "flops_per_launch": fl}
 
     # what this device sustains on a bare bf16 MFMA loop with random operands (power-limited clock), measured live
