@@ -288,6 +288,10 @@ def main():
     K_DKDV = "bwd_dkdv_slot_kernel" if bf and d == 64 else "bwd_dkdv_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
               (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
+    one_pass = bf and d == 64 and N % 256 == 0 and OPTS is not None and len(OPTS) > 4 and OPTS[4] == 2
+    if one_pass:   # A/B of the opt-in one-pass backward (--opts 0,0,0,0,2): dK/dV and dQ come from ONE kernel
+        STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
+                  ("bwd_fused_kernel", lambda: bwd(device_ops.STAGE_DKDV | device_ops.STAGE_DQ)))
     breakdown = not args.no_kernel_breakdown
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)] \
         if breakdown else None
@@ -331,7 +335,7 @@ def main():
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
         alg = {K_FWD: flops_fw, "bwd_prep_kernel": 0.0, K_DKDV: 8.0 * BH * N * N * d * cf,
-               K_DQ: 2.0 * BH * N * N * d * cf}
+               K_DQ: 2.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw}
         for i, (name, _) in enumerate(STAGES):
             ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / args.steps
             kernels[name] = (ms, alg[name])

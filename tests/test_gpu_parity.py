@@ -446,6 +446,29 @@ def test_ragged_tail_with_very_negative_logsumexp(dev, dtype, d, N):
         assert maxabs(g, ref[nm]) < tol * scale, (nm, maxabs(g, ref[nm]), scale)
 
 
+@pytest.mark.parametrize("shape,causal", [((8, 8, 4096, 64), False), ((16, 8, 2048, 34), True), ((3, 5, 1500, 64), False)])
+def test_host_abi_pipeline_multi_chunk(ops, shape, causal):
+    """The host-pointer launchers cut a call into chunks of batch*head (H2D / kernels / D2H on three streams, caller arrays pinned
+    in place): shapes that take 2-8 chunks, one with zero-padded head dim (d = 34 -> 64) and one whose chunks are ragged
+    (15 heads), forward and backward, sampled heads against the oracle."""
+    rng = np.random.default_rng(3300 + shape[2])
+    q, k, v, do = (rand_u(rng, shape) for _ in range(4))
+    o, l, m = ops.flash_attn2_fw(q, k, v, causal)
+    dq, dk, dv, _ = ops.flash_attn2_bw(q, k, v, o, do, l, m, causal)
+    B, H, N, d = shape
+    f = lambda a: a.reshape(B * H, N, -1)
+    heads = [0, B * H // 2, B * H - 1]
+    ref = oracle_heads(f(q), f(k), f(v), f(do), causal, heads)
+    assert maxabs(f(o)[heads], ref["o"]) < TOL32 and maxabs(l.reshape(B * H, N)[heads], ref["L"]) < TOL32
+    assert np.all(m == -FLT_MAX)
+    for nm, g in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert maxabs(f(g)[heads], ref[nm]) < TOL32, nm
+    # same call again with q, k, v aliased (one array registered three times cannot be pinned twice: pageable fallback)
+    o2, l2, _ = ops.flash_attn2_fw(q, q, q, causal)
+    ro, rL, _, _ = oracle.dense_attention_fw(f(q)[:1], f(q)[:1], f(q)[:1], causal)
+    assert maxabs(f(o2)[:1], ro) < TOL32 and maxabs(l2.reshape(B * H, N)[:1], rL) < TOL32
+
+
 # ---------------------------------------------------------------- row f3: flash vs vanilla attention ON THE GPU
 def _vanilla():
     import sys
