@@ -195,8 +195,20 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
     }
   }
   const int thin = (BF && causal) ? 1 : 0;
-  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
-                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau, thin);
+  // causal: key blocks p and nkb-1-p share a workgroup (uniform work, no tail: -13 % at the metric shape).  Not for the 8-wave
+  // d = 128 geometry, whose register allocation has no room for the pass loop (it would spill).
+  constexpr bool CAN_PAIR = !(BF && D == 128 && NW == 8);
+  // (MODE 3 always runs its paired build: hipcc's allocation of the unpaired MODE 3 instance spills, the paired one does not)
+  if ((causal || MODE == 3) && CAN_PAIR) {
+    if constexpr (CAN_PAIR)
+      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE, false, 1, false, true>), dim3(batch * ((nkb + 1) / 2)),
+                         dim3(NW * 64), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch,
+                         lay, causal, tau, thin);
+  } else {
+    if constexpr (MODE != 3 || !CAN_PAIR)
+      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
+                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau, thin);
+  }
   if constexpr (BF) {
     if (thin) FA_CARE_LAUNCH(false, batch, 2);
   }

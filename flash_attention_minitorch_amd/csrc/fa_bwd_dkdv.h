@@ -48,11 +48,14 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
 // CARE: the build whose per-sub-slice path splits P and dS into two bf16 fragments on rows with few admissible keys (bf16 only).
 // thin_mode (causal launches): 1 = this launch SKIPS the sub-slices of queries 0..63 (the rows with fewer than 64 keys); 2 = this
 // launch handles ONLY those (key block 0, one workgroup per batch*head, CARE build) and ADDS its dK, dV to what mode 1 stored.
-template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false, int MINW = 1, bool CARE = false>
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool HD = false, int MINW = 1, bool CARE = false, bool PAIR = false>
 __global__ void __launch_bounds__(NW * 64, MINW)   // MINW: minimum waves per SIMD the register allocation must allow
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
                 float* __restrict__ dv, int N, int nkb, int BH, Layout lay, int causal, float tau, int thin_mode = 0) {
+  // PAIR (builds for causal launches): one workgroup handles key block p and then key block nkb-1-p (heavy one first): under the causal mask
+  // key block kb sweeps nqi - kb*BK/QS query stages, so paired workgroups all do the same work and the grid has no long tail
+  // (the launcher sizes the grid with (nkb + 1) / 2 workgroups per batch*head); cf. the paired query blocks of fwd_kernel.
   using A = Atom<T>;
   typedef typename A::frag frag;
   constexpr int KC = D / 16, KT = KPW / 32, DT = D / 32, BK = NW * KPW, NT = NW * 64, NSUB = QS / 32;
@@ -63,8 +66,11 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh, kb;
-  map_block(blockIdx.x, BH, thin_mode == 2 ? 1 : nkb, bh, kb);
+  int bh, pblk;
+  map_block(blockIdx.x, BH, thin_mode == 2 ? 1 : (PAIR ? (nkb + 1) / 2 : nkb), bh, pblk);
+  const int npass = (PAIR && pblk != nkb - 1 - pblk) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int kb = (PAIR && pass == 1) ? nkb - 1 - pblk : pblk;
   const int kb0 = kb * BK, kw0 = kb0 + w * KPW;
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;   // elements between consecutive rows
@@ -579,6 +585,7 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         }
     }
   }
+  }   // pass
 }
 
 // ---------------------------------------------------------------------------------------------
