@@ -38,7 +38,7 @@ inline int d_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
 
 // Per-call kernel selection (fa_mi355x_fwd_ex / fa_mi355x_bwd_ex; every other entry point runs the defaults): [0] dK/dV geometry,
 // [1] forward kernel, [2] dQ kernel, [3] 1 = s_setprio 1 for waves 4-7 of the slot kernels, [4] 2 = one-pass backward, [5] (FA_DIAG
-// builds only) timing ablations of the one-pass backward.  The product library accepts only values whose kernels give correct
+// builds only) timing ablations of the one-pass backward, [6] 1 = causal d = 64 forward / dK/dV as main build + follow-up launch (A/B).  The product library accepts only values whose kernels give correct
 // results; stamp builds, A/B staging variants and ablations exist in the FA_DIAG build alone (libflash_attn_mi355x_diag.so, tools/).
 struct Tun { int v[8]; };
 #ifdef FA_DIAG
@@ -56,7 +56,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
   if (nopts < 0 || nopts > 8 || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
   for (int i = 0; i < nopts; ++i) t.v[i] = opts[i];
 #ifndef FA_DIAG
-  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, -1}, {0, -1}, {0, -1}};
+  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, -1}, {0, 1, -1}, {0, -1}};
   for (int i = 0; i < 8; ++i) {
     bool ok = false;
     for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
@@ -94,7 +94,7 @@ int device_cus() {
 // mask, dropout or N < 64; behind a causal launch, query block 0 alone is redone by it (one small workgroup per batch*head).
 template <typename T, int D, int BN, int WPE>
 int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
-                   fa::Layout lay, int causal, int variant, float tau, hipStream_t st, int only_qb = -1) {
+                   fa::Layout lay, int causal, int variant, float tau, hipStream_t st, int only_qb = -1, int care_main = 0) {
   constexpr bool BF = sizeof(T) == 2;
   const int nqb = (N + 127) / 128;
   const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
@@ -105,7 +105,8 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
     FA_FWD_LAUNCH(2, BF, nblk, only_qb);
   } else if (lay.kmask) {   // additive key mask: staged per tile, enters S^T as the accumulator input
     FA_FWD_LAUNCH(1, BF, nblk, only_qb);
-  } else if (BF && (N < 64 || only_qb >= 0)) {
+  } else if (BF && (N < 64 || only_qb >= 0 || (causal && care_main))) {   // care_main (d = 64): ONE launch of the split-operand build,
+    // measured 1 % faster than the main build + the block-0 follow-up launch (7.8 us); the dQ kernel is the other way round (+7 %)
     FA_FWD_LAUNCH(0, BF, nblk, only_qb);
   } else {
     FA_FWD_LAUNCH(0, false, nblk, only_qb);
@@ -160,7 +161,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
     }
   }
   return fwd_launch_cfg<T, D, (sizeof(T) == 2 ? 64 : 32), 1>(q, k, v, out, l, m, batch, N, lay, causal, variant, tau,
-                                                             st);
+                                                             st, -1, (D == 64 && tun.v[6] == 0) ? 1 : 0);
 }
 
 // bf16 launches whose rows may see fewer than 64 admissible keys everywhere (key mask, dropout, N < 64) run the split-operand
@@ -169,7 +170,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
 // adds its dK, dV (thin_mode 2): the main kernel keeps its registers and its speed.
 template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-                float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
+                float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int care_main = 0) {
   constexpr bool BF = sizeof(T) == 2;
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
   const int nkb4 = (N + 127) / 128;
@@ -190,6 +191,15 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   if constexpr (BF) {
     if (lay.kmask || N < 64) {
       FA_CARE_LAUNCH(false, batch * nkb4, 0);
+      FA_HIP_TRY(hipGetLastError());
+      return FA_OK;
+    }
+  }
+  if constexpr (BF && MODE == 3) {
+    if (causal && care_main) {   // d = 64 default: the split-operand path inside the main (paired) kernel: 2 % faster than main + corner launch
+      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE, false, 1, true, true>), dim3(batch * ((nkb + 1) / 2)),
+                         dim3(NW * 64), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch,
+                         lay, causal, tau, 0);
       FA_HIP_TRY(hipGetLastError());
       return FA_OK;
     }
@@ -219,7 +229,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
 
 template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int only_qb = -1) {
+              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int only_qb = -1, int care_main = 0) {
   constexpr bool BF = sizeof(T) == 2;   // CARE policy as fwd_launch_cfg's
   const int nqb = (N + 127) / 128;
   const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
@@ -230,7 +240,7 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
     FA_DQ_LAUNCH(2, BF, nblk, only_qb);
   } else if (lay.kmask) {
     FA_DQ_LAUNCH(1, BF, nblk, only_qb);
-  } else if (BF && (N < 64 || only_qb >= 0)) {
+  } else if (BF && (N < 64 || only_qb >= 0 || (causal && care_main))) {
     FA_DQ_LAUNCH(0, BF, nblk, only_qb);
   } else {
     FA_DQ_LAUNCH(0, false, nblk, only_qb);
@@ -351,7 +361,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = FA_OK;
       } else   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
         // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
-        rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+        rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st, tun.v[6] == 0 ? 1 : 0);
     } else if constexpr (sizeof(T) == 2) {
       if (tun.v[0] == 1)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);

@@ -114,6 +114,8 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[4]  2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
  *            head by an ordered hand-off: five products as src/flash_attn2_bw.cu:94-247, no atomics, bitwise reproducible);
  *            bf16, d = 64, non-causal, N a multiple of 256, stages containing both DKDV and DQ; other calls ignore it
+ *   opts[6]  1 = causal bf16 d = 64 forward and dK/dV: main kernels + small follow-up launches for the rows with few keys instead of
+ *            the single split-operand build (A/B; same results)
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
  * library (FA_ERR_BAD_ARG).  `stages` as fa_mi355x_bwd_stages. */
 int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
