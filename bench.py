@@ -283,8 +283,11 @@ def main():
     # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
     # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
     bf = args.dtype == "bf16" and not causal and not args.phased
-    K_FWD = "fwd_slot_kernel" if bf and ((d == 64) or (d == 128 and N % 64 == 0)) else "fwd_kernel"
-    K_DQ = "bwd_dq_slot_kernel" if bf and d == 64 else "bwd_dq_kernel"
+    # causal, d = 64, N a multiple of 256: the causal builds of the slot kernels when the launch fills the chip (fa_api.hip)
+    cwgs = BH * ((N // 256 + 1) // 2)
+    cslot = args.dtype == "bf16" and causal and not args.phased and d == 64 and N % 256 == 0
+    K_FWD = "fwd_slot_kernel" if (bf and ((d == 64) or (d == 128 and N % 64 == 0))) or (cslot and cwgs >= 256) else "fwd_kernel"
+    K_DQ = "bwd_dq_slot_kernel" if (bf and d == 64) or (cslot and cwgs >= 128) else "bwd_dq_kernel"
     K_DKDV = "bwd_dkdv_slot_kernel" if bf and d == 64 else "bwd_dkdv_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
               (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))

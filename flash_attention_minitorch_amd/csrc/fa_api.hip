@@ -78,10 +78,12 @@ inline size_t fused_extra_bytes(int batch, int N, int d) {
   const size_t groups = (size_t)std::min(batch, std::max(1, FUSED_MAX_CUS / (N / 256)));
   return FUSED_CTL_BYTES + FUSED_FLAG_BYTES + fa::FUSED_PAGES + groups * (size_t)N * 64 * sizeof(float);
 }
-int device_cus() {
+int device_cus() {   // compute units of the current device (cached per device; any thread)
+  static std::mutex mu;
   static int cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(mu);
   if (cus[dev] == 0) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -121,12 +123,16 @@ template <typename T, int D>
 int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                fa::Layout lay, int causal, int variant, float tau, hipStream_t st, const Tun& tun) {
   if constexpr (sizeof(T) == 2 && (D == 64 || D == 128)) {
-    // FA-2 side output, bf16, d = 64 / 128, non-causal: slot-interleaved three-deep pipeline.  Under the causal mask the phased
-    // kernel (128-query workgroups, per-wave tile skipping) measured 3.6 % faster, so it keeps that case; tuning key 1:
-    // 2 = always phased, 3 = always slot.
+    // FA-2 side output, bf16, d = 64 / 128, non-causal: slot-interleaved three-deep pipeline.  Under the causal mask the slot build
+    // WITH masked period variants is 3.6 % slower than the phased kernel (128-query workgroups, per-wave tile skipping), which keeps
+    // the causal launches the build below does not take; tuning key 1: 2 = always phased, 3 = always slot.
     // (N < 64: every row has few keys and takes the phased kernel's split-operand path)
-    if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3) && !lay.kmask && !lay.drop_thr && N >= 64) {
-      const int nqb = (N + 255) / 256;
+    // Causal, d = 64, N a multiple of 256: the causal slot build (unmasked sweep + the diagonal block per wave, query blocks p and
+    // nqb-1-p paired): 0.155 vs 0.192 ms for the phased kernel at the metric shape; it needs about one 8-wave workgroup per CU to pay.
+    const int nqb = (N + 255) / 256;
+    const int cwgs = batch * ((nqb + 1) / 2);
+    const bool cslot = D == 64 && causal && N % 256 == 0 && (tun.v[1] == 3 || (tun.v[1] == 0 && cwgs >= 256));
+    if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3 || cslot) && !lay.kmask && !lay.drop_thr && N >= 64) {
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
       if (whole && tun.v[1] == 93 && D == 64) {   // phase stamps (never timed)
@@ -136,6 +142,14 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
         return FA_OK;
       }
 #endif
+      if constexpr (D == 64) {
+        if (cslot) {
+          hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4, true>), dim3(cwgs), dim3(512), 0, st, (const T*)q,
+                             (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
+          FA_HIP_TRY(hipGetLastError());
+          return FA_OK;
+        }
+      }
       if (whole && tun.v[1] != 6 && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)
         hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
@@ -255,7 +269,10 @@ template <typename T, int D, int DIAG = 0>
 int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                    float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
   const int nqb = (N + 255) / 256;
-  if (DIAG == 0 && !causal && N % 128 == 0)   // no sub-tile needs a mask: the build without masked period variants
+  if (DIAG == 0 && causal && N % 256 == 0)   // causal build: unmasked sweep + the diagonal block per wave, paired query blocks
+    hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), dim3(batch * ((nqb + 1) / 2)), dim3(512), 0, st, (const T*)q,
+                       (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+  else if (DIAG == 0 && !causal && N % 128 == 0)   // no sub-tile needs a mask: the build without masked period variants
     hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
   else
@@ -413,8 +430,11 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
       if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || (causal && tun.v[2] != 3) || N < 64)   // key mask and dropout live in the
-        // phased kernel, which is also 1 % faster under the causal mask (tuning key 2 = 3 forces the slot kernel)
+      else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || N < 64 ||
+               (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * ((N / 256 + 1) / 2) >= 128)))
+        // key mask and dropout live in the phased kernel, which is also 1 % faster than the slot build WITH masked periods under
+        // the causal mask (tuning key 2 = 3 forces the slot kernel).  Causal launches with N a multiple of 256 take the causal slot
+        // build (unmasked sweep + diagonal block per wave, paired query blocks): 0.199 vs 0.223 ms at the metric shape
         rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
 #ifdef FA_DIAG
       else if (tun.v[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
@@ -424,8 +444,9 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 #endif
       else {
         rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-        // forced onto a causal launch: rows 0..63 (few keys) are redone by the phased kernel's split-operand path (query block 0)
-        if (!rc && causal) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);
+        // the masked slot build forced onto a causal launch: rows 0..63 (few keys) are redone by the phased kernel's split-operand
+        // path (query block 0); the causal slot build (N a multiple of 256) splits them itself
+        if (!rc && causal && N % 256 != 0) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);
       }
     } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
       if (tun.v[2] == 1)

@@ -225,7 +225,12 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // ---------------------------------------------------------------------------------------------
 // MASKS = false: non-causal launch with N a multiple of 128 (no sub-tile ever needs a mask): the masked period variants and
 // their register pressure at the joins disappear.
-template <typename T, int D, int DIAG = 0, bool MASKS = true>
+// CDIAG = true (MASKS = false, N a multiple of 256): the causal launch, as fwd_slot_kernel's: the pipeline sweeps the 2 * qb full
+// stages in front of the workgroup's first query without a mask; the 256 keys of its own diagonal block are the next two stages of
+// the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles
+// 0..w and masks the last one; rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p
+// share a workgroup (uniform work).
+template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                    const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
@@ -233,7 +238,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
   using A = Atom<T>;
   typedef typename A::frag frag;
-  constexpr int KC = D / 16, ST = 128, NT = 512;
+  constexpr int KC = D / 16, ST = 128;
   constexpr int TB = A::template tile_bytes<D>(ST);   // 16 KiB
   constexpr int VOFF = 3 * TB;                        // V slot = K slot + 48 KiB
   __shared__ __attribute__((aligned(16))) char smem_raw[6 * TB];
@@ -241,19 +246,22 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh, qb;
-  map_block(blockIdx.x, BH, nqb, bh, qb);
-  if (causal) qb = nqb - 1 - qb;
-  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
-  const bool qvalid = qrow < N;
+  static_assert(!CDIAG || (!MASKS && DIAG == 0), "causal build: unmasked sweep + diagonal block");
+  const int nblk = CDIAG ? (nqb + 1) / 2 : nqb;
+  int bh, pblk;
+  map_block(blockIdx.x, BH, nblk, bh, pblk);
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
-  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
-  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
   const float c = tau * LOG2E;
+  const int npass = (CDIAG && pblk != nqb - 1 - pblk) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qb = CDIAG ? (pass == 0 ? nqb - 1 - pblk : pblk) : (causal ? nqb - 1 - pblk : pblk);
+  if (CDIAG && pass) __syncthreads();   // every wave is done with the diagonal stages of the first block
+  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
+  const bool qvalid = qrow < N;
 
   frag qf[KC], dof[KC];
 #pragma unroll
@@ -276,7 +284,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
-  const int kmax = causal ? min(N, qb * 256 + 256) : N;
+  const int kmax = CDIAG ? qb * 256 : (causal ? min(N, qb * 256 + 256) : N);
   const int nstage = (kmax + ST - 1) / ST;
   // Stage loads go global -> LDS directly (buffer_load ... lds, 1 KiB = 8 rows per wave-instruction, no staging
   // registers): LDS-DMA writes lane-linearly, so the image's chunk swizzle is applied to each lane's SOURCE address.
@@ -305,6 +313,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     for (int off = tid * 16; off < 6 * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
   }
+  if (!CDIAG || nstage > 0) {   // (causal build: query block 0 has no key in front of its diagonal block)
   stage_dma(0, 0);
   dma_wait_all();   // this wave's pieces have landed
   __syncthreads();
@@ -437,7 +446,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     const bool more = st + 1 < nstage;
     const int nb = slot_of(st + 1);
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;   // rows of the next stage
-    if (more) stage_dma((st + 1) * ST, nb);
+    if (CDIAG || more) stage_dma((st + 1) * ST, nb);   // (causal build: the diagonal block follows the sweep)
     const int kb = st * ST;
     // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
     auto need = [&](int sub) { return MASKS && ((kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0)); };
@@ -461,6 +470,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     if constexpr (DIAG == 1) { t0 = stamp(); ph[2] += t0 - t1; }
     if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
     if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+    if (CDIAG && !more) stage_dma((st + 2) * ST, slot_of(st + 2));   // second diagonal stage: its slot was last read one period ago
     // period 4st+2: produce sub 3, consume sub 2, dQ of sub 1; rows two ahead = sub 0 of the next stage
     if constexpr (MASKS) {
       if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
@@ -481,6 +491,59 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   }
   // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
   period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+  }
+
+  if constexpr (CDIAG) {
+    // The diagonal block: keys kmax .. kmax + 255 = stages nstage, nstage + 1 of the ring (slots nstage % 3, (nstage + 1) % 3).
+    if (nstage == 0) {
+      stage_dma(0, 0);
+      stage_dma(ST, TB);
+    }
+    dma_wait_all();
+    __syncthreads();
+    const bool careful = A::SPLITS && q0 < 64;   // wave-uniform
+    for (int j = 0; j <= w; ++j) {
+      const int sb = ((nstage + (j >> 2)) % 3) * TB;
+      lds_char* tk = smem + sb;
+      lds_char* tv = tk + VOFF;
+      const int row32 = 32 * (j & 3);
+      f32x16 s, dp;
+      A::mma_c(s, A::template row_frag<D>(tk, ra, row32, 0), qf[0], zero16());
+      A::mma_c(dp, A::template row_frag<D>(tv, ra, row32, 0), dof[0], nd16);
+#pragma unroll
+      for (int kc = 1; kc < KC; ++kc) {
+        A::mma(s, A::template row_frag<D>(tk, ra, row32, kc), qf[kc]);
+        A::mma(dp, A::template row_frag<D>(tv, ra, row32, kc), dof[kc]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nlq));
+      if (j == w) {   // this wave's own 32 keys: key kmax + 32 * w + row against query q0 + r
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (acc_row(i, h) > r) s[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dp[i] = s[i] * dp[i];
+      const frag ds0 = A::pack(dp, 0), ds1 = A::pack(dp, 1);
+      if (!careful) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            A::mma(acc[dt], A::template tr_frag<D>(tk, ta, row32 + 16 * s2, dt), s2 ? ds1 : ds0);
+      } else {   // rows with fewer than 64 admissible keys: K^T dS^T also takes what the bf16 rounding of dS dropped
+        const frag dl0 = A::pack_lo(dp, 0, ds0), dl1 = A::pack_lo(dp, 1, ds1);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const frag kt_ = A::template tr_frag<D>(tk, ta, row32 + 16 * s2, dt);
+            A::mma(acc[dt], kt_, s2 ? ds1 : ds0);
+            A::mma(acc[dt], kt_, s2 ? dl1 : dl0);
+          }
+      }
+    }
+  }
 
   if constexpr (DIAG == 1) {
     const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
@@ -507,6 +570,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
         *reinterpret_cast<f32x4*>(row + 32 * dt + 8 * g + 4 * hh) = val;
       }
   }
+  }   // pass
 }
 
 

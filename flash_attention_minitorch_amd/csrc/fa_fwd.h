@@ -289,7 +289,13 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 // which removes the masked period variants and their register pressure at the joins (needed at d = 128).
 // STK: keys per stage (default: 16 KiB of K and of V); MINW: waves per SIMD the register allocation must allow (STK = 64 at
 // d = 64 halves the rings to 64 KiB, two workgroups per CU = four waves per SIMD at <= 128 VGPRs).
-template <typename T, int D, bool MASKS = true, int DIAG = 0, int STK = 8192 / D, int MINW = 2>
+// CDIAG = true (MASKS = false, 64-key stages, N a multiple of 256): the causal launch.  The pipeline above sweeps the keys in
+// front of the workgroup's first query (4 * qb full stages, no sub-tile of them needs a mask, so the unmasked build keeps its
+// registers and its four waves per SIMD); the 256 keys of the workgroup's own diagonal block are the NEXT four stages of the same
+// ring (prefetched by the last iterations) and are then taken wave by wave the classic way (true maximum, reference moved):
+// wave w multiplies sub-tiles 0..w of the block and masks the last one.  Rows 0..63 (fewer than 64 admissible keys) split P
+// into two bf16 fragments there (Atom::pack_lo), which is what the phased CARE build does for them.
+template <typename T, int D, bool MASKS = true, int DIAG = 0, int STK = 8192 / D, int MINW = 2, bool CDIAG = false>
 __global__ void __launch_bounds__(512, MINW)
 fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
                 float* __restrict__ aux_l, int N, int nqb, int BH, Layout lay, int causal, float tau) {
@@ -305,22 +311,29 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   constexpr int VOFF = R * TB;
   constexpr int SUBB = (D / 32) * 512 * 4;            // bytes of one 32-key sub-tile inside a stage image
   static_assert((TB == 16384 || TB == 8192) && 2 * DT == KC && (NSUBT == 2 || NSUBT == 4), "stage geometry");
+  static_assert(!CDIAG || (!MASKS && NSUBT == 2 && R * ST == 256), "causal build: the ring holds one 256-key diagonal block");
   __shared__ __attribute__((aligned(16))) char smem_raw[2 * R * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh, qb;
-  map_block(blockIdx.x, BH, nqb, bh, qb);
-  if (causal) qb = nqb - 1 - qb;
-  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
-  const bool qvalid = qrow < N;
+  // The causal build pairs query block p with block nqb-1-p in one workgroup (heavy one first): every workgroup sweeps the same
+  // number of stages (the launcher sizes the grid with (nqb + 1) / 2 blocks per batch*head).
+  const int nblk = CDIAG ? (nqb + 1) / 2 : nqb;
+  int bh, pblk;
+  map_block(blockIdx.x, BH, nblk, bh, pblk);
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const raw_rsrc_t kraw = make_raw_rsrc(k + base, mat_bytes), vraw = make_raw_rsrc(v + base, mat_bytes);
   const float c = tau * LOG2E;
+  const int npass = (CDIAG && pblk != nqb - 1 - pblk) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int qb = CDIAG ? (pass == 0 ? nqb - 1 - pblk : pblk) : (causal ? nqb - 1 - pblk : pblk);
+  if (CDIAG && pass) __syncthreads();   // every wave is done with the diagonal image of the first block
+  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
+  const bool qvalid = qrow < N;
 
   frag qf[KC];
 #pragma unroll
@@ -332,7 +345,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
-  const int kmax = causal ? min(N, qb * 256 + 256) : N;
+  const int kmax = CDIAG ? qb * 256 : (causal ? min(N, qb * 256 + 256) : N);
   const int nstage = (kmax + ST - 1) / ST;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)smem;
   // LDS-DMA pieces of 1 KiB: d = 64: one 8-row group (piece = w, w + 8); d = 128: half of one (piece = 2 * group + half).
@@ -364,6 +377,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     for (int off = tid * 16; off < 2 * R * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
   }
+  if (!CDIAG || nstage > 0) {   // (causal build: query block 0 has no key in front of its diagonal block)
   stage_dma(0, 0);
   if (NSUBT == 2 && nstage > 1) stage_dma(ST, slot_of(1));
   dma_wait_all();
@@ -561,7 +575,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         dma_wait_all();
         __syncthreads();
       }
-      if (st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));
+      if (CDIAG || st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));   // (causal build: the diagonal block follows)
       // period 2st+0: produce sub 1, softmax of sub 0, P.V of sub 1 of the previous stage; rows two ahead: next stage, sub 0
       if constexpr (MASKS) {
         if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, nr0, nr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
@@ -583,6 +597,84 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   }
   // drain: P.V of the last sub-tile (the buffers alternate per sub-tile: an even count per stage ends on B)
   period(T0, T0, T1, T0, ic<0>{}, ic<NSUBT - 1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
+  }
+
+  if constexpr (CDIAG) {
+    // The diagonal block: keys kmax .. kmax + 255 = stages nstage .. nstage + 3 of the ring = slots 0 .. 3 (nstage % 4 == 0), i.e.
+    // ONE 256-row image of K at smem and of V at smem + VOFF.  Stages nstage, nstage + 1 were requested by the sweep.
+    if (nstage == 0) {
+      stage_dma(0, 0);
+      stage_dma(ST, TB);
+    }
+    dma_wait_all();
+    __syncthreads();   // slots 0, 1 published; every wave is past its last read of slots 2, 3
+    stage_dma(kmax + 2 * ST, 2 * TB);
+    stage_dma(kmax + 3 * ST, 3 * TB);
+    const bool careful = A::SPLITS && q0 < 64;   // wave-uniform
+    auto diag_tile = [&](int j, bool first) {
+      f32x16 s;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const frag kk = A::template row_frag<D>(smem, ra, 32 * j, kc);
+        if (kc == 0) A::mma_c(s, kk, qf[0], zero16());
+        else A::mma(s, kk, qf[kc]);
+      }
+      if (j == w) {   // this wave's own 32 keys: key kmax + 32 * w + row against query q0 + r
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (acc_row(i, h) > r) s[i] = -INFINITY;
+      }
+      float mx = s[0];   // finite: the sub-tile's first key is admissible for every row
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+      mx = xhalf_max(mx);
+      float alpha = 1.0f;
+      if (first) {
+        m_ref = mx;
+      } else {
+        const float delta = fmaxf(mx - m_ref, 0.f);
+        if (__any(delta > 0.f)) {
+          alpha = __builtin_amdgcn_exp2f(-delta * c);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
+          m_ref += delta;
+        }
+      }
+      nmc = -m_ref * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nmc));
+        rs += s[i];
+      }
+      l_run = l_run * alpha + rs;
+      const frag pf0 = A::pack(s, 0), pf1 = A::pack(s, 1);
+      if (!careful) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            A::mma(acc_o[dt], A::template tr_frag<D>(smem + VOFF, ta, 32 * j + 16 * s2, dt), s2 ? pf1 : pf0);
+      } else {   // rows with fewer than 64 admissible keys: P.V also takes what the bf16 rounding of P dropped
+        const frag pl0 = A::pack_lo(s, 0, pf0), pl1 = A::pack_lo(s, 1, pf1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const frag vt = A::template tr_frag<D>(smem + VOFF, ta, 32 * j + 16 * s2, dt);
+            A::mma(acc_o[dt], vt, s2 ? pf1 : pf0);
+            A::mma(acc_o[dt], vt, s2 ? pl1 : pl0);
+          }
+      }
+    };
+    const int jmid = min(w, 3);
+    for (int j = 0; j <= jmid; ++j) diag_tile(j, nstage == 0 && j == 0);
+    dma_wait_all();
+    __syncthreads();   // slots 2, 3 published
+    for (int j = 4; j <= w; ++j) diag_tile(j, false);
+  }
 
   if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
   const float l_tot = xhalf_sum(l_run);
@@ -610,6 +702,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
     }
   }
+  }   // pass
 }
 
 

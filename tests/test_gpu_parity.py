@@ -226,12 +226,14 @@ def test_device_path_small_shapes(dev, dtype, d, N, causal):
         assert maxabs(to_np(dv), ref["dv"]) < tol
 
 
-@pytest.mark.parametrize("N", [255, 256, 257, 513, 1000])
+@pytest.mark.parametrize("N", [255, 256, 257, 512, 513, 768, 1000, 1280, 2048])
 @pytest.mark.parametrize("causal", [False, True])
 def test_slot_kernels_block_and_ring_boundaries(dev, N, causal):
     """bf16, d = 64, FA-2: the slot-interleaved forward / dQ / dK-dV kernels around their structural boundaries --
     256-query workgroups, 128-key stages, the three-slot K/V ring wrapping (>= 4 stages), ragged tails and the causal
-    diagonal inside a stage -- each compared with the phased kernels (tuning keys) and with the oracle."""
+    diagonal inside a stage -- each compared with the phased kernels (tuning keys) and with the oracle.  Causal with N a
+    multiple of 256 runs the causal builds of the forward / dQ slot kernels (unmasked sweep + the diagonal block per wave,
+    query blocks p and nqb-1-p paired: one, an odd and an even number of blocks, rings wrapping); other N the masked builds."""
     import torch
     from flash_attention_minitorch_amd import _lib
     rng = np.random.default_rng(7000 + N)
@@ -673,17 +675,19 @@ def test_online_softmax_rescale_branch_is_exercised(dev):
     arrs = [oracle.bf16_round(a) for a in (q, k, v, do)]
     for causal in (False, True):
         for tdt, tol in ((torch.bfloat16, TOLBF), (torch.float32, TOL32)):
-            t = [torch.from_numpy(a).to("cuda", tdt) for a in arrs]
-            o, L, _ = dev.flash_attn_fwd(*t[:3], causal=causal)
-            dq, dk, dv = dev.flash_attn_bwd(*t[:3], o, t[3], L, causal=causal)
-            ref = oracle_heads(*arrs, causal, range(BH))
-            for nm, got in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
-                # the spiked keys make |K| ~ 12 and gather P ~ 1 from many rows, so gradients reach O(10):
-                # the tolerance is relative to the tensor's scale here
-                # (the spiked rows put nearly all their weight on ONE key, so bf16 P / dS are not averaged: 5e-3)
-                scale = max(1.0, float(np.max(np.abs(ref[nm]))))
-                t = (5e-3 if tdt == torch.bfloat16 else tol) * scale
-                assert maxabs(to_np(got), ref[nm]) < t, (causal, tdt, nm, maxabs(to_np(got), ref[nm]), scale)
+            # (0, 3, 3): the slot kernels whatever the launch size (causal, N = 512: the diagonal-block phase moves the reference)
+            for opts in ((None, (0, 3, 3)) if tdt == torch.bfloat16 else (None,)):
+                t = [torch.from_numpy(a).to("cuda", tdt) for a in arrs]
+                o, L, _ = dev.flash_attn_fwd(*t[:3], causal=causal, opts=opts)
+                dq, dk, dv = dev.flash_attn_bwd(*t[:3], o, t[3], L, causal=causal, opts=opts)
+                ref = oracle_heads(*arrs, causal, range(BH))
+                for nm, got in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
+                    # the spiked keys make |K| ~ 12 and gather P ~ 1 from many rows, so gradients reach O(10):
+                    # the tolerance is relative to the tensor's scale here
+                    # (the spiked rows put nearly all their weight on ONE key, so bf16 P / dS are not averaged: 5e-3)
+                    scale = max(1.0, float(np.max(np.abs(ref[nm]))))
+                    lim = (5e-3 if tdt == torch.bfloat16 else tol) * scale
+                    assert maxabs(to_np(got), ref[nm]) < lim, (causal, tdt, opts, nm, maxabs(to_np(got), ref[nm]), scale)
 
 
 @pytest.mark.parametrize("N", [200, 256])   # ragged (masked slot builds / phased) and stage-aligned (mask-free slot builds)
