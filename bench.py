@@ -94,6 +94,18 @@ def run_extras(torch, device_ops, q, k, v, do, causal):
     r["vanilla"] = "torch-ROCm materialised S: bf16 matmuls (hipBLASLt), fp32 softmax, autograd backward; device resident"
     out["vs_vanilla"] = {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in r.items()}
     torch.cuda.empty_cache()
+    # --- the reference's "breakup" figure (kernel_tests/test_flashattn_breakdown.py:44-66: B=8 H=8 d=64 fp32, causal mask on):
+    # per-phase time of the vanilla forward beside the one fused launch, at N = 2048 (the S tensor is 1 GiB in fp32)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    mk32 = lambda: (torch.rand((64, 2048, 64), device="cuda", generator=gen) - 0.5) * 2
+    q32, k32, v32 = mk32(), mk32(), mk32()
+    bd = vg.vanilla_breakdown_ms(q32, k32, v32, True)
+    o32, l32, _ = device_ops.flash_attn_fwd(q32, k32, v32, True)
+    bd["fused_flash_attn2_fw"] = vg.time_ms(lambda: device_ops.flash_attn_fwd(q32, k32, v32, True, out=o32, l=l32), 10, 3)
+    out["vs_vanilla"]["breakdown_ms"] = {"shape": "B8 H8 N2048 d64 fp32 causal (reference timing harness shape)",
+                                         **{kk: round(vv, 4) for kk, vv in bd.items()}}
+    del q32, k32, v32, o32, l32
+    torch.cuda.empty_cache()
 
     # --- per-variant [total, fw, bw]
     def three(B, H, N_, d_, tdt, variant, caus):

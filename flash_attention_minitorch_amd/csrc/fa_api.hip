@@ -131,7 +131,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
     // nqb-1-p paired): 0.155 vs 0.192 ms for the phased kernel at the metric shape; it needs about one 8-wave workgroup per CU to pay.
     const int nqb = (N + 255) / 256;
     const int cwgs = batch * ((nqb + 1) / 2);
-    const bool cslot = D == 64 && causal && N % 256 == 0 && (tun.v[1] == 3 || (tun.v[1] == 0 && cwgs >= 256));
+    const bool cslot = causal && N % 256 == 0 && (tun.v[1] == 3 || (tun.v[1] == 0 && cwgs >= 256));
     if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3 || cslot) && !lay.kmask && !lay.drop_thr && N >= 64) {
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
@@ -142,13 +142,11 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
         return FA_OK;
       }
 #endif
-      if constexpr (D == 64) {
-        if (cslot) {
-          hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4, true>), dim3(cwgs), dim3(512), 0, st, (const T*)q,
-                             (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
-          FA_HIP_TRY(hipGetLastError());
-          return FA_OK;
-        }
+      if (cslot) {   // (d = 64: four waves per SIMD, two workgroups per CU; d = 128: two waves per SIMD, one workgroup)
+        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>), dim3(cwgs), dim3(512), 0, st,
+                           (const T*)q, (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
+        FA_HIP_TRY(hipGetLastError());
+        return FA_OK;
       }
       if (whole && tun.v[1] != 6 && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)

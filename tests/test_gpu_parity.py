@@ -367,6 +367,24 @@ def test_forward_slot_kernel_d128(dev, N):
     assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF   # (see the comment above)
 
 
+@pytest.mark.parametrize("N", [256, 768, 1024, 2304])
+def test_causal_forward_slot_kernel_d128(dev, N):
+    """bf16, d = 128, FA-2, causal, N a multiple of 256: the causal build of the slot-interleaved forward (unmasked sweep of the
+    keys in front of the workgroup's diagonal block, the block wave by wave, query blocks p and nqb-1-p paired; option 1 = 3
+    forces it whatever the launch size) against the phased kernel and the oracle: 1, 3, 4 and 9 query blocks."""
+    import torch
+    rng = np.random.default_rng(8100 + N)
+    BH, d = 3, 128
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(3)]
+    tq, tk, tv = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    ro, rL, _, _ = oracle.dense_attention_fw(*arrs, causal=True)
+    o_s, l_s, _ = dev.flash_attn_fwd(tq, tk, tv, causal=True, opts=(0, 3))
+    o_p, l_p, _ = dev.flash_attn_fwd(tq, tk, tv, causal=True, opts=(0, 2))
+    assert maxabs(to_np(o_s), ro) < TOLBF and maxabs(to_np(l_s), rL) < TOLBF
+    assert maxabs(to_np(o_p), ro) < TOLBF and maxabs(to_np(l_p), rL) < TOLBF
+    assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF
+
+
 @pytest.mark.parametrize("BH,N", [(1, 256), (3, 512), (5, 768), (2, 2048), (20, 1024)])
 def test_one_pass_backward_matches_oracle_and_two_kernel_path(dev, BH, N):
     """The opt-in one-pass backward (csrc/fa_bwd_fused.h: dQ formed in the key-stationary kernel, summed across the N/256

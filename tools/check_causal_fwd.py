@@ -21,7 +21,7 @@ def check(B, H, N, d=64, seed=0, heads=(0,), scale=1.0):
     qf, kf, vf = (oracle.bf16_round((sc * rng.uniform(-1, 1, (B * H, N, d))).astype(np.float32)) for sc in (scale, 1.0, 1.0))
     tq, tk, tv = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in (qf, kf, vf))
     ok = True
-    msg = [f"B{B} H{H} N{N} scale {scale}"]
+    msg = [f"B{B} H{H} N{N} d{d} scale {scale}"]
     outs = {}
     for name, opts in VARIANTS.items():
         o, L, _ = device_ops.flash_attn_fwd(tq, tk, tv, causal=True, opts=opts)
@@ -65,7 +65,7 @@ def timeit(B, H, N, d=64, iters=50):
     e1.record()
     torch.cuda.synchronize()
     res["noncausal_half"] = round(e0.elapsed_time(e1) / iters / 2, 4)
-    print(f"time B{B} H{H} N{N}: {res}", flush=True)
+    print(f"time B{B} H{H} N{N} d{d}: {res}", flush=True)
 
 
 if __name__ == "__main__":
@@ -73,7 +73,11 @@ if __name__ == "__main__":
     for shape in ((1, 2, 256), (1, 2, 512), (1, 3, 768), (2, 2, 1024), (1, 2, 1280), (1, 1, 4096)):
         ok &= check(*shape)
     ok &= check(1, 2, 1024, seed=3, scale=3.0)   # larger scores: the reference moves in the diagonal block
+    for shape in ((1, 2, 256), (1, 3, 768), (2, 2, 1024), (1, 1, 4096)):
+        ok &= check(*shape, d=128)
     if "--time" in sys.argv:
         for shape in ((8, 8, 4096), (8, 8, 2048), (8, 8, 1024), (8, 8, 512), (2, 8, 4096), (1, 8, 8192), (4, 8, 1024), (16, 8, 512)):
             timeit(*shape)
+        timeit(16, 16, 4096, d=128, iters=10)
+        timeit(8, 8, 4096, d=128, iters=20)
     sys.exit(0 if ok else 1)

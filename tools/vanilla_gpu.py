@@ -29,6 +29,37 @@ def vanilla_fw_bw(q, k, v, do, causal):
     return o.detach(), qq.grad, kk.grad, vv.grad
 
 
+def vanilla_breakdown_ms(q, k, v, causal=True, iters=5):
+    """Per-phase time of the vanilla forward, the phases of the reference's breakdown harness
+    (kernel_tests/test_flashattn_breakdown.py:44-66): qk = (q @ kT) / sqrt(d); mask = build the causal mask and add it;
+    softmax; dropout = multiply by a ones "drop" matrix (what the harness does); pv = P @ v.  HIP events between the phases,
+    device resident, mean of ``iters`` runs after one warm-up.  Matmuls in the inputs' dtype, the rest in fp32."""
+    n, d = q.shape[-2], q.shape[-1]
+    names = ("qk", "mask", "softmax", "dropout", "pv")
+    acc = dict.fromkeys(names, 0.0)
+    drop = torch.ones((n, n), dtype=torch.float32, device=q.device)
+    for it in range(iters + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev[0].record()
+        s = torch.matmul(q, k.transpose(-1, -2)).float() * (d ** -0.5)
+        ev[1].record()
+        if causal:
+            s = s + causal_mask(n, q.device)
+        ev[2].record()
+        p = torch.softmax(s, dim=-1)
+        ev[3].record()
+        p = drop * p
+        ev[4].record()
+        o = torch.matmul(p.to(v.dtype), v)
+        ev[5].record()
+        torch.cuda.synchronize()
+        if it:   # the first run is the warm-up
+            for i, nm in enumerate(names):
+                acc[nm] += ev[i].elapsed_time(ev[i + 1]) / iters
+        del s, p, o
+    return acc
+
+
 def time_ms(fn, iters=5, warm=1):
     for _ in range(warm):
         fn()
