@@ -296,11 +296,11 @@ def main():
     # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
     bf = args.dtype == "bf16" and not causal and not args.phased
     # causal, d = 64, N a multiple of 256: the causal builds of the slot kernels when the launch fills the chip (fa_api.hip)
-    cwgs = BH * ((N // 256 + 1) // 2)
+    cblocks = BH * (N // 256)
     cslot = args.dtype == "bf16" and causal and not args.phased and d == 64 and N % 256 == 0
-    K_FWD = "fwd_slot_kernel" if (bf and ((d == 64) or (d == 128 and N % 64 == 0))) or (cslot and cwgs >= 256) else "fwd_kernel"
-    K_DQ = "bwd_dq_slot_kernel" if (bf and d == 64) or (cslot and cwgs >= 128) else "bwd_dq_kernel"
-    K_DKDV = "bwd_dkdv_slot_kernel" if bf and d == 64 else "bwd_dkdv_kernel"
+    K_FWD = "fwd_slot_kernel" if (bf and ((d == 64) or (d == 128 and N % 64 == 0))) or (cslot and cblocks >= 256) else "fwd_kernel"
+    K_DQ = "bwd_dq_slot_kernel" if (bf and d == 64) or (cslot and cblocks >= 128) else "bwd_dq_kernel"
+    K_DKDV = "bwd_dkdv_slot_kernel" if (bf and d == 64) or (cslot and cblocks >= 128) else "bwd_dkdv_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
               (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
     one_pass = bf and d == 64 and N % 256 == 0 and OPTS is not None and len(OPTS) > 4 and OPTS[4] == 2

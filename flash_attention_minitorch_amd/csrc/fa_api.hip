@@ -56,7 +56,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
   if (nopts < 0 || nopts > 8 || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
   for (int i = 0; i < nopts; ++i) t.v[i] = opts[i];
 #ifndef FA_DIAG
-  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, -1}, {0, 1, -1}, {0, -1}};
+  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, -1}, {0, 1, -1}, {0, 1, 2, -1}};
   for (int i = 0; i < 8; ++i) {
     bool ok = false;
     for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
@@ -90,6 +90,21 @@ int device_cus() {   // compute units of the current device (cached per device; 
     cus[dev] = n;
   }
   return cus[dev];
+}
+
+// Causal slot builds: heads per XCD dispatched together, longest block first (fa::map_block_ranked): a chunk of two rounds of the chip
+int rank_chunk(int wgs_per_cu, int nb) {
+  const int cus = device_cus();
+  return std::max(1, (cus > 0 ? cus : 256) * wgs_per_cu / (4 * nb));
+}
+
+// Causal slot builds of the forward / dQ kernels: one block per workgroup in ranked order (measured 1-20 % faster than paired blocks
+// up to 4 rounds of the chip, 1-2 % slower from 16 rounds on: B = 32 at the metric shape, configs[3]) or blocks p and nqb-1-p paired
+// in one workgroup.  Option 7: 0 = by launch size, 1 = paired, 2 = ranked.
+bool causal_ranked(const Tun& tun, int blocks, int wgs_per_cu) {
+  if (tun.v[7]) return tun.v[7] == 2;
+  const int cus = device_cus();
+  return blocks < 8 * (cus > 0 ? cus : 256) * wgs_per_cu;
 }
 
 // Phased forward.  bf16 rows with fewer than 64 admissible keys need the split-operand build (CARE): whole launches under a key
@@ -130,8 +145,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
     // Causal, d = 64, N a multiple of 256: the causal slot build (unmasked sweep + the diagonal block per wave, query blocks p and
     // nqb-1-p paired): 0.155 vs 0.192 ms for the phased kernel at the metric shape; it needs about one 8-wave workgroup per CU to pay.
     const int nqb = (N + 255) / 256;
-    const int cwgs = batch * ((nqb + 1) / 2);
-    const bool cslot = causal && N % 256 == 0 && (tun.v[1] == 3 || (tun.v[1] == 0 && cwgs >= 256));
+    const bool cslot = causal && N % 256 == 0 && (tun.v[1] == 3 || (tun.v[1] == 0 && batch * nqb >= 256));
     if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3 || cslot) && !lay.kmask && !lay.drop_thr && N >= 64) {
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
@@ -143,8 +157,11 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       }
 #endif
       if (cslot) {   // (d = 64: four waves per SIMD, two workgroups per CU; d = 128: two waves per SIMD, one workgroup)
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>), dim3(cwgs), dim3(512), 0, st,
-                           (const T*)q, (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
+        const bool ranked = causal_ranked(tun, batch * nqb, D == 64 ? 2 : 1);
+        lay.rank_chunk = rank_chunk(D == 64 ? 2 : 1, nqb);
+        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>),
+                           dim3(ranked ? batch * nqb : batch * ((nqb + 1) / 2)),
+                           dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, ranked ? 2 : 1, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
@@ -265,11 +282,14 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
 
 template <typename T, int D, int DIAG = 0>
 int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-                   float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st) {
+                   float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, const Tun& tun = default_tun()) {
   const int nqb = (N + 255) / 256;
-  if (DIAG == 0 && causal && N % 256 == 0)   // causal build: unmasked sweep + the diagonal block per wave, paired query blocks
-    hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), dim3(batch * ((nqb + 1) / 2)), dim3(512), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+  lay.rank_chunk = rank_chunk(1, nqb);
+  const bool paired = !causal_ranked(tun, batch * nqb, 1);
+  if (DIAG == 0 && causal && N % 256 == 0)   // causal build: unmasked sweep + the diagonal block per wave; one block per workgroup,
+    // longest first across all heads (paired: blocks p and nqb-1-p in one workgroup)
+    hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), dim3(paired ? batch * ((nqb + 1) / 2) : batch * nqb), dim3(512),
+                       0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau);
   else if (DIAG == 0 && !causal && N % 128 == 0)   // no sub-tile needs a mask: the build without masked period variants
     hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                        (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
@@ -374,6 +394,16 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         }
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
+      } else if (D == 64 && causal && !lay.drop_thr && !lay.kmask && N % 256 == 0 &&
+                 (tun.v[0] == 5 || (tun.v[0] == 0 && batch * (N / 256) >= 128))) {   // (tuning key 0 = 5 forces it)
+        // d = 64, causal, N a multiple of 256: the causal build of the continuous pipeline (sweep of the stages below the
+        // diagonal block, the block per wave, workgroups longest first); tuning key 0 = 3: the phased kernel below
+        const int nkb = N / 256;
+        lay.rank_chunk = rank_chunk(1, nkb);
+        hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        FA_HIP_TRY(hipGetLastError());
+        rc = FA_OK;
       } else   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
         // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
         rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st, tun.v[6] == 0 ? 1 : 0);
@@ -429,7 +459,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       if (tun.v[2] == 1)
         rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
       else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || N < 64 ||
-               (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * ((N / 256 + 1) / 2) >= 128)))
+               (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * (N / 256) >= 128)))
         // key mask and dropout live in the phased kernel, which is also 1 % faster than the slot build WITH masked periods under
         // the causal mask (tuning key 2 = 3 forces the slot kernel).  Causal launches with N a multiple of 256 take the causal slot
         // build (unmasked sweep + diagonal block per wave, paired query blocks): 0.199 vs 0.223 ms at the metric shape
@@ -441,7 +471,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
 #endif
       else {
-        rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+        rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun);
         // the masked slot build forced onto a causal launch: rows 0..63 (few keys) are redone by the phased kernel's split-operand
         // path (query block 0); the causal slot build (N a multiple of 256) splits them itself
         if (!rc && causal && N % 256 != 0) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);

@@ -297,6 +297,7 @@ struct Layout {
   float drop_scale;      // kept probabilities are multiplied by this (1 = minitorch's nn.dropout, 1/(1-rate) = inverted)
   uint32_t drop_seed;
   int young_prio;        // slot kernels: waves 4-7 of a workgroup run at s_setprio 1 (0 = off); scheduling only
+  int rank_chunk;        // causal slot builds: heads per XCD whose blocks are dispatched together, longest first (map_block_ranked)
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two
@@ -329,6 +330,23 @@ FA_DEV void map_block(int id, int BH, int nb, int& bh, int& b) {
   } else {
     bh = id / nb;
     b = id % nb;
+  }
+}
+
+// Causal launches: block rank b = 0 is the heaviest block of every (batch*head) (the caller maps rank -> block).  The heads of an
+// XCD are taken in chunks of C; within a chunk all blocks of rank 0 are dispatched first, then rank 1, ...: longest first, so the
+// dynamic assignment of workgroups to CUs ends level (the work per rank falls linearly: a chunk of two rounds of the chip pairs
+// rank r with rank nb-1-r by itself), while only C heads per XCD stream their K / V (Q / dO) through its L2 at a time.
+FA_DEV void map_block_ranked(int id, int BH, int nb, int C, int& bh, int& b) {
+  if ((BH & 7) == 0) {
+    const int xcd = id & 7, slot = id >> 3, per = BH >> 3;
+    const int chunk = slot / (C * nb), within = slot - chunk * (C * nb);
+    const int cper = min(C, per - chunk * C);   // (the last chunk of an XCD may be smaller)
+    bh = xcd * per + chunk * C + within % cper;
+    b = within / cper;
+  } else {
+    bh = id % BH;
+    b = id / BH;
   }
 }
 

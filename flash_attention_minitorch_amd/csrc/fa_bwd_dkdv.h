@@ -597,7 +597,12 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 // (sub-slice 0 of stage s+1 is first requested in period 2), and its DMA is issued at the top of stage s into the slot of
 // stage s-2, which every wave left before that barrier of stage s-1.  No compiler-tracked global load in the loop.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int DIAG = 0>
+// CDIAG = true (N a multiple of 256): the causal launch.  Key block kb sweeps the query stages BELOW its diagonal block (stages
+// 2 * (kb + 1) .. nst - 1, no sub-slice of them needs a mask) through the pipeline; the two stages of the diagonal block itself
+// follow in the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-slice form: wave w multiplies
+// sub-slices w..7 of the block and masks the first one; queries 0..63 split P and dS into two bf16 fragments there
+// (Atom::pack_lo).  Workgroups are ranked longest-first across all heads (map_block_ranked), so the grid ends level.
+template <typename T, int D, int DIAG = 0, bool CDIAG = false>
 __global__ void __launch_bounds__(512)
 bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                      const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
@@ -614,10 +619,10 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bh, kb;
-  map_block(blockIdx.x, BH, nkb, bh, kb);
-  const int kw0 = kb * BK + w * KPW;
-  const bool active = kw0 < N;   // wave-uniform: a wave whose keys all lie past N only moves data and joins the barriers
+  static_assert(!CDIAG || DIAG == 0, "causal build: no stamps");
+  int bh, kb;   // (causal build: key block 0 sweeps the most query stages: the heaviest blocks of all heads are dispatched first)
+  if (CDIAG) map_block_ranked(blockIdx.x, BH, nkb, max(lay.rank_chunk, 1), bh, kb);
+  else map_block(blockIdx.x, BH, nkb, bh, kb);
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
@@ -627,6 +632,8 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   const raw_rsrc_t nlraw = make_raw_rsrc(nlc + (size_t)bh * N, (uint32_t)N * 4u);
   const raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
   const float c = tau * LOG2E;
+  const int kw0 = kb * BK + w * KPW;
+  const bool active = kw0 < N;   // wave-uniform: a wave whose keys all lie past N only moves data and joins the barriers
 
   frag kf[KC], vf[KC];
 #pragma unroll
@@ -671,7 +678,9 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
   }
-  stage_dma(0, 0);
+  const int st0 = CDIAG ? 2 * (kb + 1) : 0;   // first stage of the sweep (causal build: the stage below the diagonal block)
+  if (!CDIAG || st0 < nst) {
+  stage_dma(st0, slot_of(st0));
   dma_wait_all();
   __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
@@ -791,7 +800,8 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   };
   auto T1 = ic<1>{};
   auto T0 = ic<0>{};
-  int cr0 = ra.b[0], cr1 = ra.b[1], ct0 = ta.b[0], ct1 = ta.b[1], ch16 = 16 * h;   // addresses of the current stage (slot 0)
+  const int b0 = slot_of(st0);   // addresses of the current stage
+  int cr0 = ra.b[0] + b0, cr1 = ra.b[1] + b0, ct0 = ta.b[0] + b0, ct1 = ta.b[1] + b0, ch16 = 16 * h + b0;
   if (active) {
     // operands of sub-slice 0, then its S', dP' alone (the pipeline fills)
 #pragma unroll
@@ -802,10 +812,11 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     SB();
     period(T1, T0, ic<0>{}, ic<0>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sA, dpA, sB, dpB);
   }
-  for (int st = 0; st < nst; ++st) {
+  for (int st = st0; st < nst; ++st) {
     const int nb = slot_of(st + 1);
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb, nh16 = 16 * h + nb;
     if (st + 1 < nst) stage_dma(st + 1, nb);
+    else if (CDIAG) stage_dma(2 * kb, nb);   // the first stage of the diagonal block follows the sweep in the ring
     if (active) {
       period(T1, T1, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sB, dpB, sA, dpA);
       period(T1, T1, ic<2>{}, ic<1>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sA, dpA, sB, dpB);
@@ -815,6 +826,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
     __syncthreads();
     if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+    if (CDIAG && st + 1 == nst) stage_dma(2 * kb + 1, slot_of(nst + 1));   // second diagonal stage: the slot of stage nst-2 is free now
     if (active) {
       // sub-slice 0 of the next stage is requested from here on (after the last stage: stale data, results unused)
       period(T1, T1, ic<3>{}, ic<2>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, nh16, sB, dpB, sA, dpA);
@@ -822,6 +834,79 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     }
     cr0 = nr0; cr1 = nr1; ch16 = nh16;
     ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
+  }
+  }
+  if constexpr (CDIAG) {
+    // The diagonal block: queries kb * 256 .. + 255 = stages 2 * kb, 2 * kb + 1, in the ring slots of stages nst, nst + 1.
+    if (st0 >= nst) {   // (the last key block has no stage below its diagonal block)
+      stage_dma(2 * kb, slot_of(nst));
+      stage_dma(2 * kb + 1, slot_of(nst + 1));
+    }
+    dma_wait_all();
+    __syncthreads();
+    for (int j = w; j < 8; ++j) {
+      lds_char* tq = smem + slot_of(nst + (j >> 2));
+      lds_char* tdo = tq + TB;
+      const int sub = j & 3;
+      const int qi0 = kb * BK + 32 * j;
+      f32x16 nl16, nd16;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a = *FA_LDS(f32x4, tq + 2 * TB + 128 * sub + 16 * h + 32 * g);
+        const f32x4 b = *FA_LDS(f32x4, tq + 2 * TB + 4 * QS + 128 * sub + 16 * h + 32 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          nl16[4 * g + i] = a[i];
+          nd16[4 * g + i] = b[i];
+        }
+      }
+      f32x16 s, dp;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const frag aq = A::template row_frag<D>(tq, ra, 32 * sub, kc);
+        const frag ado = A::template row_frag<D>(tdo, ra, 32 * sub, kc);
+        if (kc == 0) {   // row constants ride in as accumulator inputs: S' = S - L/tau, dP' = dP - delta
+          A::mma_c(s, aq, kf[kc], nl16);
+          A::mma_c(dp, ado, vf[kc], nd16);
+        } else {
+          A::mma(s, aq, kf[kc]);
+          A::mma(dp, ado, vf[kc]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, km));
+      if (j == w) {   // this wave's own 32 queries: key kw0 + r against query qi0 + row
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (r > acc_row(i, h)) s[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dp[i] = s[i] * dp[i];
+      const frag pf0 = A::pack(s, 0), pf1 = A::pack(s, 1), ds0 = A::pack(dp, 0), ds1 = A::pack(dp, 1);
+      if (!(A::SPLITS && qi0 < 64)) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            A::mma(acc_dv[dt], A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt), s2 ? pf1 : pf0);
+            A::mma(acc_dk[dt], A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt), s2 ? ds1 : ds0);
+          }
+      } else {   // queries with fewer than 64 admissible keys: both products also take what the bf16 rounding of P, dS dropped
+        const frag pl0 = A::pack_lo(s, 0, pf0), pl1 = A::pack_lo(s, 1, pf1);
+        const frag dl0 = A::pack_lo(dp, 0, ds0), dl1 = A::pack_lo(dp, 1, ds1);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const frag adoT = A::template tr_frag<D>(tdo, ta, 32 * sub + 16 * s2, dt);
+            const frag aqT = A::template tr_frag<D>(tq, ta, 32 * sub + 16 * s2, dt);
+            A::mma(acc_dv[dt], adoT, s2 ? pf1 : pf0);
+            A::mma(acc_dv[dt], adoT, s2 ? pl1 : pl0);
+            A::mma(acc_dk[dt], aqT, s2 ? ds1 : ds0);
+            A::mma(acc_dk[dt], aqT, s2 ? dl1 : dl0);
+          }
+      }
+    }
   }
   if constexpr (DIAG) {
     const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();

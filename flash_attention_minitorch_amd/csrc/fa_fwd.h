@@ -319,16 +319,18 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // The causal build pairs query block p with block nqb-1-p in one workgroup (heavy one first): every workgroup sweeps the same
   // number of stages (the launcher sizes the grid with (nqb + 1) / 2 blocks per batch*head).
-  const int nblk = CDIAG ? (nqb + 1) / 2 : nqb;
+  const bool ranked = CDIAG && causal == 2;   // A/B: one block per workgroup, heaviest blocks of all heads first
+  const int nblk = (CDIAG && !ranked) ? (nqb + 1) / 2 : nqb;
   int bh, pblk;
-  map_block(blockIdx.x, BH, nblk, bh, pblk);
+  if (ranked) map_block_ranked(blockIdx.x, BH, nblk, max(lay.rank_chunk, 1), bh, pblk);
+  else map_block(blockIdx.x, BH, nblk, bh, pblk);
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const raw_rsrc_t kraw = make_raw_rsrc(k + base, mat_bytes), vraw = make_raw_rsrc(v + base, mat_bytes);
   const float c = tau * LOG2E;
-  const int npass = (CDIAG && pblk != nqb - 1 - pblk) ? 2 : 1;
+  const int npass = (CDIAG && !ranked && pblk != nqb - 1 - pblk) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   const int qb = CDIAG ? (pass == 0 ? nqb - 1 - pblk : pblk) : (causal ? nqb - 1 - pblk : pblk);
   if (CDIAG && pass) __syncthreads();   // every wave is done with the diagonal image of the first block

@@ -107,15 +107,19 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
                          void* stream);
 
 /* Forward / backward with per-call kernel options (no process-wide state): opts[0..nopts-1], nopts <= 8, 0 = default.
- *   opts[0]  dK/dV kernel geometry: 1, 2, 4, 5 = the alternatives measured in profiles/README.md; 3 = the causal slot path
- *   opts[1]  forward kernel: 2 = phased, 3 = slot kernel also under the causal mask, 6 = 128-key stages
+ *   opts[0]  dK/dV kernel geometry: 1, 2, 4, 5 = the alternatives measured in profiles/README.md; 3 = the phased kernel with the slot
+ *            path on unmasked stages (what causal launches ran before the causal build of the continuous pipeline); 5 at
+ *            d = 64, causal, N % 256 == 0: that causal build whatever the launch size
+ *   opts[1]  forward kernel: 2 = phased, 3 = slot kernel also under the causal mask (whatever the launch size), 6 = 128-key stages
  *   opts[2]  dQ kernel: 1 / 2 / 4 = phased with 64- / 32-key tiles / 4 waves, 3 = slot kernel also under the causal mask
  *   opts[3]  1 = waves 4-7 of the slot kernels run at s_setprio 1
  *   opts[4]  2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
  *            head by an ordered hand-off: five products as src/flash_attn2_bw.cu:94-247, no atomics, bitwise reproducible);
  *            bf16, d = 64, non-causal, N a multiple of 256, stages containing both DKDV and DQ; other calls ignore it
- *   opts[6]  1 = causal bf16 d = 64 forward and dK/dV: main kernels + small follow-up launches for the rows with few keys instead of
- *            the single split-operand build (A/B; same results)
+ *   opts[6]  1 = causal bf16 d = 64 forward and dK/dV (phased kernels): main kernels + small follow-up launches for the rows with few
+ *            keys instead of the single split-operand build (A/B; same results)
+ *   opts[7]  causal builds of the forward / dQ slot kernels: 1 = query blocks p and nqb-1-p paired in one workgroup, 2 = one block
+ *            per workgroup dispatched longest first; 0 = by launch size (ranked below 8 rounds of the chip)
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
  * library (FA_ERR_BAD_ARG).  `stages` as fa_mi355x_bwd_stages. */
 int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,

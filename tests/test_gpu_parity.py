@@ -243,13 +243,21 @@ def test_slot_kernels_block_and_ring_boundaries(dev, N, causal):
     tol = TOLBF_CAUSAL if causal else TOLBF
     ref = oracle_heads(*arrs, causal, range(BH))
     outs = {}
-    for tag, opts in (("slot", (0, 3, 3)), ("phased", dev.OPTS_PHASED)):   # 3 forces the slot kernels under the causal mask too
+    # options 1, 2 = 3 / option 0 = 5 force the slot kernels under the causal mask whatever the launch size; option 7: causal builds
+    # with one block per workgroup in ranked order (2) or with blocks p and nqb-1-p paired (1)
+    k0 = 5 if causal else 0
+    variants = [("slot", (k0, 3, 3, 0, 0, 0, 0, 2)), ("phased", dev.OPTS_PHASED)]
+    if causal and N % 256 == 0:
+        variants.append(("slot_paired", (k0, 3, 3, 0, 0, 0, 0, 1)))
+    for tag, opts in variants:
         o, l, m = dev.flash_attn_fwd(tq, tk, tv, causal=causal, opts=opts)
         dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, m, causal=causal, opts=opts)
         outs[tag] = [to_np(x) for x in (o, l, dq, dk, dv)]
-    for nm, got in zip(("o", "L", "dq", "dk", "dv"), outs["slot"]):
-        assert np.all(np.isfinite(got)), nm
-        assert maxabs(got, ref[nm]) < tol, (nm, maxabs(got, ref[nm]))
+    for tag in outs:
+        if tag != "phased":
+            for nm, got in zip(("o", "L", "dq", "dk", "dv"), outs[tag]):
+                assert np.all(np.isfinite(got)), (tag, nm)
+                assert maxabs(got, ref[nm]) < tol, (tag, nm, maxabs(got, ref[nm]))
     # same arithmetic per element, different tiling of the key loop: the two builds agree far inside the tolerance
     for nm, a, b in zip(("o", "L", "dq", "dk", "dv"), outs["slot"], outs["phased"]):
         assert maxabs(a, b) < 0.5 * tol, (nm, maxabs(a, b))
@@ -694,7 +702,7 @@ def test_online_softmax_rescale_branch_is_exercised(dev):
     for causal in (False, True):
         for tdt, tol in ((torch.bfloat16, TOLBF), (torch.float32, TOL32)):
             # (0, 3, 3): the slot kernels whatever the launch size (causal, N = 512: the diagonal-block phase moves the reference)
-            for opts in ((None, (0, 3, 3)) if tdt == torch.bfloat16 else (None,)):
+            for opts in ((None, (5 if causal else 0, 3, 3)) if tdt == torch.bfloat16 else (None,)):
                 t = [torch.from_numpy(a).to("cuda", tdt) for a in arrs]
                 o, L, _ = dev.flash_attn_fwd(*t[:3], causal=causal, opts=opts)
                 dq, dk, dv = dev.flash_attn_bwd(*t[:3], o, t[3], L, causal=causal, opts=opts)

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from flash_attention_minitorch_amd import device_ops  # noqa: E402
 
-VARIANTS = {"phased": (0, 0, 2), "slot": (0, 0, 3)}
+VARIANTS = {"phased": (3, 0, 2), "slot": (5, 0, 3), "slot_paired": (5, 0, 3, 0, 0, 0, 0, 1), "slot_ranked": (5, 0, 3, 0, 0, 0, 0, 2)}   # key 0 = 3: phased dK/dV
 NAMES = ("dq", "dk", "dv")
 
 
@@ -37,7 +37,7 @@ def check(B, H, N, d=64, seed=0, heads=(0,), scale=1.0):
         fin = all(bool(np.isfinite(a).all()) for a in res[name])
         ok &= fin and max(errs) <= 1e-3
         msg.append(f"{name}: " + " ".join(f"{n} {e:.2e}" for n, e in zip(NAMES, errs)) + f" finite {fin}")
-    msg.append(f"|slot-phased| dq {float(np.max(np.abs(res['slot'][0] - res['phased'][0]))):.2e}")
+    msg.append("|slot-phased| " + " ".join(f"{n} {float(np.max(np.abs(a - b))):.2e}" for n, a, b in zip(NAMES, res["slot"], res["phased"])))
     print(("OK   " if ok else "FAIL ") + " | ".join(msg), flush=True)
     return ok
 
@@ -70,7 +70,10 @@ def timeit(B, H, N, d=64, iters=50):
         for name, opts in VARIANTS.items():
             res[f"dq_{name}{rnd}"] = t(True, device_ops.STAGE_DQ, opts)
     res["dq_noncausal_half"] = round(t(False, device_ops.STAGE_DQ, None) / 2, 4)
-    res["dkdv_causal"] = t(True, device_ops.STAGE_DKDV, None)
+    res["dkdv_causal_phased"] = t(True, device_ops.STAGE_DKDV, (3,))
+    res["dkdv_causal_slot"] = t(True, device_ops.STAGE_DKDV, None)
+    res["dkdv_causal_phased1"] = t(True, device_ops.STAGE_DKDV, (3,))
+    res["dkdv_causal_slot1"] = t(True, device_ops.STAGE_DKDV, None)
     res["dkdv_noncausal_half"] = round(t(False, device_ops.STAGE_DKDV, None) / 2, 4)
     print(f"time B{B} H{H} N{N}: {res}", flush=True)
 

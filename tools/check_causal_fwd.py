@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from flash_attention_minitorch_amd import device_ops  # noqa: E402
 
-VARIANTS = {"default": (0, 2), "slot": (0, 3)}   # phased (split-operand build) vs causal slot build
+VARIANTS = {"default": (0, 2), "slot": (0, 3), "slot_paired": (0, 3, 0, 0, 0, 0, 0, 1), "slot_ranked": (0, 3, 0, 0, 0, 0, 0, 2)}   # phased (split-operand build) vs causal slot build
 
 
 def check(B, H, N, d=64, seed=0, heads=(0,), scale=1.0):
@@ -76,7 +76,7 @@ if __name__ == "__main__":
     for shape in ((1, 2, 256), (1, 3, 768), (2, 2, 1024), (1, 1, 4096)):
         ok &= check(*shape, d=128)
     if "--time" in sys.argv:
-        for shape in ((8, 8, 4096), (8, 8, 2048), (8, 8, 1024), (8, 8, 512), (2, 8, 4096), (1, 8, 8192), (4, 8, 1024), (16, 8, 512)):
+        for shape in ((8, 8, 4096), (32, 8, 4096), (8, 8, 2048), (8, 8, 1024), (2, 8, 4096), (1, 8, 8192), (16, 8, 512)):
             timeit(*shape)
         timeit(16, 16, 4096, d=128, iters=10)
         timeit(8, 8, 4096, d=128, iters=20)
