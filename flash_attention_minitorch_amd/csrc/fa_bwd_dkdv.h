@@ -682,6 +682,11 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   if (!CDIAG || st0 < nst) {
   stage_dma(st0, slot_of(st0));
   dma_wait_all();
+  // The K / V fragments are tracked loads whose first use sits behind `if (active)`: without an unconditional use HERE (where
+  // everything has landed anyway) hipcc re-emits their s_waitcnt vmcnt(7..0) inside the stage loop, where they wait out the
+  // LDS-DMA of the next stage that the loop has just issued.
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(kf[kc]), "v"(vf[kc]));
   __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
