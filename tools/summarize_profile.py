@@ -77,7 +77,8 @@ if pmc:
             traffic[n] = int(rd + wr)
             detail[n] = {"FETCH_SIZE_KB_per_launch": dd["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": dd["WRITE_SIZE"],
                          "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr}
-    if traffic and not tag.endswith("ph"):   # a '...ph' tag is the phased-kernel A/B profile: keep hbm_traffic.json on the shipped kernels
+    if traffic and not tag.endswith("ph") and "causal" not in tag:   # '...ph' (phased-kernel A/B) and causal profiles leave hbm_traffic.json
+        # (which bench.py quotes for the non-causal metric shape) alone
         print("hbm bytes per launch:", traffic)
         traffic["_detail"] = detail
         traffic["_note"] = ("bytes per launch at B=8,H=8,N=4096,d=64 bf16; FETCH_SIZE (KB) x 1024 x 2 (gfx950 wide-read correction) + "
