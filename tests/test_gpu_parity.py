@@ -375,6 +375,33 @@ def test_forward_slot_kernel_d128(dev, N):
     assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF   # (see the comment above)
 
 
+@pytest.mark.parametrize("BH,N", [(24, 512), (5, 768), (40, 256), (16, 2560), (72, 1024)])
+@pytest.mark.parametrize("order", [1, 2])
+def test_causal_slot_builds_block_order(dev, BH, N, order):
+    """The causal builds of the slot kernels map workgroup ids to (batch*head, block) either paired (option 7 = 1: blocks p and
+    nqb-1-p in one workgroup) or ranked (2: one block per workgroup, heads taken in chunks per XCD, longest block first): every
+    block of every head must be visited exactly once whatever batch*head (a multiple of 8 or not, fewer or more heads per XCD than
+    a chunk) and the block count (odd, even, more than a chunk's share).  All heads against the phased kernels (same arithmetic
+    per element), three heads against the oracle."""
+    import torch
+    rng = np.random.default_rng(9000 + BH + N)
+    d = 64
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    outs = {}
+    for tag, opts in (("slot", (5, 3, 3, 0, 0, 0, 0, order)), ("phased", dev.OPTS_PHASED)):
+        o, l, _ = dev.flash_attn_fwd(tq, tk, tv, causal=True, opts=opts)
+        dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, None, causal=True, opts=opts)
+        outs[tag] = [to_np(x) for x in (o, l, dq, dk, dv)]
+    for nm, a, b in zip(("o", "L", "dq", "dk", "dv"), outs["slot"], outs["phased"]):
+        assert np.all(np.isfinite(a)), nm
+        assert maxabs(a, b) < TOLBF, (nm, maxabs(a, b))
+    heads = [0, BH // 2, BH - 1]
+    ref = oracle_heads(*arrs, True, heads)
+    for nm, got in zip(("o", "L", "dq", "dk", "dv"), outs["slot"]):
+        assert maxabs(got[heads], ref[nm]) < TOLBF, (nm, maxabs(got[heads], ref[nm]))
+
+
 @pytest.mark.parametrize("N", [256, 768, 1024, 2304])
 def test_causal_forward_slot_kernel_d128(dev, N):
     """bf16, d = 128, FA-2, causal, N a multiple of 256: the causal build of the slot-interleaved forward (unmasked sweep of the
