@@ -56,7 +56,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
   if (nopts < 0 || nopts > 8 || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
   for (int i = 0; i < nopts; ++i) t.v[i] = opts[i];
 #ifndef FA_DIAG
-  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, -1}, {0, 1, -1}, {0, 1, 2, -1}};
+  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, 1, -1}, {0, 1, -1}, {0, 1, 2, -1}};
   for (int i = 0; i < 8; ++i) {
     bool ok = false;
     for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
@@ -388,7 +388,19 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // d = 64, non-causal default: the continuous slot pipeline (no drain at stage boundaries, three-slot LDS-DMA ring);
         // rows thinned by a key mask or N < 64 go to the kernel below, whose per-sub-slice path splits P and dS
         const int nkb = (N + 255) / 256;
-        {
+        // Key block kb of several consecutive heads per workgroup (the tiled build: no set-up, no wait for K / V fragments and
+        // stage 0, no store drain between them) while the grid still covers every CU; option 5 = 1: one head per workgroup
+        int tiles = 1;
+        if (N % 256 == 0 && tun.v[5] == 0) {
+          const int cus = std::max(device_cus(), 1);
+          for (int t = 2; t <= 16; ++t)
+            if (batch % t == 0 && (batch / t) % 8 == 0 && (long)(batch / t) * nkb >= cus) tiles = t;
+        }
+        if (tiles > 1) {
+          lay.tiles = tiles;
+          hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
+                             (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        } else {
           hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                              (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
         }

@@ -298,6 +298,7 @@ struct Layout {
   uint32_t drop_seed;
   int young_prio;        // slot kernels: waves 4-7 of a workgroup run at s_setprio 1 (0 = off); scheduling only
   int rank_chunk;        // causal slot builds: heads per XCD whose blocks are dispatched together, longest first (map_block_ranked)
+  int tiles;             // tiled dK/dV build: consecutive heads per workgroup
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two

@@ -602,7 +602,15 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 // follow in the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-slice form: wave w multiplies
 // sub-slices w..7 of the block and masks the first one; queries 0..63 split P and dS into two bf16 fragments there
 // (Atom::pack_lo).  Workgroups are ranked longest-first across all heads (map_block_ranked), so the grid ends level.
-template <typename T, int D, int DIAG = 0, bool CDIAG = false>
+// TILED = true (non-causal, N a multiple of 256): a workgroup takes key block kb of lay.tiles CONSECUTIVE HEADS, one after the
+// other, without leaving the pipeline's ring (the workgroups of all key blocks of a head group move from head to head together, so
+// a head's Q / dO stream is still shared through the XCD's L2; consecutive key blocks of ONE head per workgroup lost that sharing
+// and measured 9 % slower at B = 32): the last stage iteration of a head requests stage 0 of the next head into the next ring slot,
+// the next head's K / V fragments are requested before the dK / dV stores of the finished one are issued, and nothing waits for
+// those stores.  In-kernel stamps (tools/phase_cycles.py 393) put the un-overlapped head and tail of a
+// one-block workgroup at 8 % of its life (1.6 k cycles of set-up, 5.5 k waiting for fragments and stage 0, 7 k until the stores
+// have drained, of 200 k): with one workgroup per CU nothing else runs there meanwhile.
+template <typename T, int D, int DIAG = 0, bool CDIAG = false, bool TILED = false>
 __global__ void __launch_bounds__(512)
 bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                      const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
@@ -620,28 +628,36 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   static_assert(!CDIAG || DIAG == 0, "causal build: no stamps");
+  unsigned long long k_t00 = 0;
+  if constexpr (DIAG) k_t00 = stamp();   // first instruction of the wave
+  static_assert(!TILED || (!CDIAG && DIAG == 0), "tiled build: non-causal, no stamps");
+  const int tiles = TILED ? max(lay.tiles, 1) : 1;   // heads per workgroup (the launcher sizes the grid with BH / tiles head groups)
   int bh, kb;   // (causal build: key block 0 sweeps the most query stages: the heaviest blocks of all heads are dispatched first)
   if (CDIAG) map_block_ranked(blockIdx.x, BH, nkb, max(lay.rank_chunk, 1), bh, kb);
-  else map_block(blockIdx.x, BH, nkb, bh, kb);
-  const size_t base = head_base(lay, bh);
+  else map_block(blockIdx.x, BH / tiles, nkb, bh, kb);
+  bh *= tiles;
+  size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
-  const rsrc_t krs = make_rsrc(k + base, mat_bytes);
-  const rsrc_t vrs = make_rsrc(v + base, mat_bytes);
-  const raw_rsrc_t qraw = make_raw_rsrc(q + base, mat_bytes), doraw = make_raw_rsrc(dout + base, mat_bytes);
-  const raw_rsrc_t nlraw = make_raw_rsrc(nlc + (size_t)bh * N, (uint32_t)N * 4u);
-  const raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
+  rsrc_t krs = make_rsrc(k + base, mat_bytes);
+  rsrc_t vrs = make_rsrc(v + base, mat_bytes);
+  raw_rsrc_t qraw = make_raw_rsrc(q + base, mat_bytes), doraw = make_raw_rsrc(dout + base, mat_bytes);
+  raw_rsrc_t nlraw = make_raw_rsrc(nlc + (size_t)bh * N, (uint32_t)N * 4u);
+  raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
   const float c = tau * LOG2E;
   const int kw0 = kb * BK + w * KPW;
   const bool active = kw0 < N;   // wave-uniform: a wave whose keys all lie past N only moves data and joins the barriers
-
+                                 // (tiled build: N is a multiple of 256, every wave of every block is active)
   frag kf[KC], vf[KC];
+  auto load_kv = [&](int k0) {
 #pragma unroll
-  for (int kc = 0; kc < KC; ++kc) {
-    const int off = ((kw0 + r) * ld + 16 * kc + 8 * h) * (int)sizeof(T);   // rows >= N read as zero
-    kf[kc] = load_frag_buf<T>(krs, off);
-    vf[kc] = load_frag_buf<T>(vrs, off);
-  }
+    for (int kc = 0; kc < KC; ++kc) {
+      const int off = ((k0 + r) * ld + 16 * kc + 8 * h) * (int)sizeof(T);   // rows >= N read as zero
+      kf[kc] = load_frag_buf<T>(krs, off);
+      vf[kc] = load_frag_buf<T>(vrs, off);
+    }
+  };
+  load_kv(kw0);
   const int key = kw0 + r;
   const float km = (lay.kmask != nullptr && key < N) ? lay.kmask[(size_t)(bh / lay.mask_heads) * N + key] * LOG2E : 0.f;
   f32x16 acc_dk[2], acc_dv[2];
@@ -672,7 +688,8 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
            (st * QS + 64 * half) * 4);
     }
   };
-  auto slot_of = [&](int st) { return (st % 3) * BUF; };
+  int roff = 0;   // tiled build: ring position of the current block's stage 0
+  auto slot_of = [&](int st) { return ((st + roff) % 3) * BUF; };
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
   if constexpr (DIAG) {
     k_t0 = stamp();
@@ -682,6 +699,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   if (!CDIAG || st0 < nst) {
   stage_dma(st0, slot_of(st0));
   dma_wait_all();
+  if constexpr (DIAG) { ph[4] = k_t0 - k_t00; ph[5] = stamp() - k_t0; }   // set-up + fragment-load issue; wait for fragments + stage 0
   // The K / V fragments are tracked loads whose first use sits behind `if (active)`: without an unconditional use HERE (where
   // everything has landed anyway) hipcc re-emits their s_waitcnt vmcnt(7..0) inside the stage loop, where they wait out the
   // LDS-DMA of the next stage that the loop has just issued.
@@ -805,6 +823,11 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   };
   auto T1 = ic<1>{};
   auto T0 = ic<0>{};
+  for (int t = 0; t < tiles; ++t) {
+  if (TILED && t) {   // the fragments of this head were requested before the previous head's stores (see below)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(kf[kc]), "v"(vf[kc]));
+  }
   const int b0 = slot_of(st0);   // addresses of the current stage
   int cr0 = ra.b[0] + b0, cr1 = ra.b[1] + b0, ct0 = ta.b[0] + b0, ct1 = ta.b[1] + b0, ch16 = 16 * h + b0;
   if (active) {
@@ -822,6 +845,14 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb, nh16 = 16 * h + nb;
     if (st + 1 < nst) stage_dma(st + 1, nb);
     else if (CDIAG) stage_dma(2 * kb, nb);   // the first stage of the diagonal block follows the sweep in the ring
+    else if (TILED && t + 1 < tiles) {   // the next head's sweep: its stage 0 follows in the ring
+      const size_t nbase = head_base(lay, bh + 1);
+      qraw = make_raw_rsrc(q + nbase, mat_bytes);
+      doraw = make_raw_rsrc(dout + nbase, mat_bytes);
+      nlraw = make_raw_rsrc(nlc + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
+      ndraw = make_raw_rsrc(ndelta + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
+      stage_dma(0, nb);
+    }
     if (active) {
       period(T1, T1, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sB, dpB, sA, dpA);
       period(T1, T1, ic<2>{}, ic<1>{}, ic<3>{}, cr0, cr1, ct0, ct1, cr0, cr1, ch16, sA, dpA, sB, dpB);
@@ -840,6 +871,35 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     cr0 = nr0; cr1 = nr1; ch16 = nh16;
     ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
   }
+  if constexpr (TILED) {   // hand over to the next head: its fragments are requested before this head's stores are issued
+    // (requesting them a stage ahead into spare registers, so that the pipeline never refills, spilled: 256 VGPRs + 128 B)
+    float* dkrow = dk + base + (size_t)key * ld;
+    float* dvrow = dv + base + (size_t)key * ld;
+    if (t + 1 < tiles) {
+      ++bh;
+      base = head_base(lay, bh);
+      krs = make_rsrc(k + base, mat_bytes);
+      vrs = make_rsrc(v + base, mat_bytes);
+      load_kv(kw0);
+      roff = (roff + nst) % 3;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a = {acc_dk[dt][4 * g] * tau, acc_dk[dt][4 * g + 1] * tau, acc_dk[dt][4 * g + 2] * tau, acc_dk[dt][4 * g + 3] * tau};
+        f32x4 b = {acc_dv[dt][4 * g], acc_dv[dt][4 * g + 1], acc_dv[dt][4 * g + 2], acc_dv[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h) = a;
+        *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h) = b;
+      }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      acc_dk[dt] = zero16();
+      acc_dv[dt] = zero16();
+    }
+  }
+  }   // heads of this workgroup
+  if constexpr (TILED) return;
   }
   if constexpr (CDIAG) {
     // The diagonal block: queries kb * 256 .. + 255 = stages 2 * kb, 2 * kb + 1, in the ring slots of stages nst, nst + 1.
@@ -913,16 +973,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
       }
     }
   }
-  if constexpr (DIAG) {
-    const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
-    ph[1] += k_t1 - t0;
-    const int slot = blockIdx.x * 8 + w;
-    if (slot < 8192 && lane == 0) {
-      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
-      g_phase_cycles[slot * 8 + 6] = k_t1 - k_t0;
-      g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
-    }
-  }
+  if constexpr (DIAG) ph[1] += stamp() - t0;
   if (key < N) {
     float* dkrow = dk + base + (size_t)key * ld;
     float* dvrow = dv + base + (size_t)key * ld;
@@ -935,6 +986,16 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
         *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h) = a;
         *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h) = b;
       }
+  }
+  if constexpr (DIAG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left: upper bound of the epilogue
+    const unsigned long long k_t2 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
+    const int slot = blockIdx.x * 8 + w;
+    if (slot < 8192 && lane == 0) {
+      for (int j = 0; j < 6; ++j) g_phase_cycles[slot * 8 + j] = ph[j];
+      g_phase_cycles[slot * 8 + 6] = k_t2 - k_t00;   // wave lifetime, first instruction to stores drained
+      g_phase_cycles[slot * 8 + 7] = k_r1 - k_r0;
+    }
   }
 }
 

@@ -116,6 +116,8 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[4]  2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
  *            head by an ordered hand-off: five products as src/flash_attn2_bw.cu:94-247, no atomics, bitwise reproducible);
  *            bf16, d = 64, non-causal, N a multiple of 256, stages containing both DKDV and DQ; other calls ignore it
+ *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
+ *            per workgroup when the launch still covers every CU; bitwise the same results)
  *   opts[6]  1 = causal bf16 d = 64 forward and dK/dV (phased kernels): main kernels + small follow-up launches for the rows with few
  *            keys instead of the single split-operand build (A/B; same results)
  *   opts[7]  causal builds of the forward / dQ slot kernels: 1 = query blocks p and nqb-1-p paired in one workgroup, 2 = one block

@@ -375,6 +375,28 @@ def test_forward_slot_kernel_d128(dev, N):
     assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF and maxabs(to_np(l_s), to_np(l_p)) < 0.5 * TOLBF   # (see the comment above)
 
 
+@pytest.mark.parametrize("BH,N", [(256, 512), (512, 256), (64, 4096), (320, 1024)])
+def test_tiled_dkdv_build_is_bitwise_the_one_head_build(dev, BH, N):
+    """bf16, d = 64, non-causal, N a multiple of 256, launches of at least one workgroup per CU per head group: the dK/dV slot
+    kernel's tiled build (key block kb of 2 / 2 / 4 / 5 consecutive heads per workgroup, the ring and the pipeline carried from head
+    to head) against the one-head-per-workgroup build (option 5 = 1): the same arithmetic in the same order, so bit for bit; two
+    heads (the first of a group and the last one) against the oracle."""
+    import torch
+    rng = np.random.default_rng(9100 + BH + N)
+    d = 64
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    o, l, _ = dev.flash_attn_fwd(tq, tk, tv)
+    tiled = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l)]
+    plain = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, opts=(0, 0, 0, 0, 0, 1))]
+    for nm, a, b in zip(("dq", "dk", "dv"), tiled, plain):
+        assert np.array_equal(a, b), nm
+    heads = [0, BH - 1]
+    ref = oracle_heads(*arrs, False, heads)
+    for nm, got in zip(("dq", "dk", "dv"), tiled):
+        assert maxabs(got[heads], ref[nm]) < TOLBF, (nm, maxabs(got[heads], ref[nm]))
+
+
 @pytest.mark.parametrize("BH,N", [(24, 512), (5, 768), (40, 256), (16, 2560), (72, 1024)])
 @pytest.mark.parametrize("order", [1, 2])
 def test_causal_slot_builds_block_order(dev, BH, N, order):

@@ -38,7 +38,11 @@ if MODE == 193:
     names = ["prologue (Q load, first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier",
              "epilogue (normalise, store O and L)", "-"]
 elif MODE == 393:
-    names = ["prologue (K/V fragments, first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier", "-", "-"]
+    # [4] and [5] lie inside / in front of [0]: [4] = first instruction -> fragment loads issued (before the prologue stamp),
+    # [5] = prologue stamp -> fragments and stage 0 landed (the rest of [0] is the barrier); lifetime runs from the first instruction
+    # to the dK / dV stores drained, so lifetime - sum([0..3]) - [4] = the epilogue
+    names = ["prologue (K/V fragments, first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier",
+             "(set-up: first instruction -> K/V loads issued)", "(of the prologue: wait for fragments + stage 0)"]
 elif MODE == 293:
     names = ["prologue (first stage DMA + barrier)", "periods (MFMA slots)", "vmcnt(0) wait for own DMA", "barrier", "-", "-"]
 elif MODE == 93:
@@ -47,6 +51,11 @@ elif MODE == 93:
 else:
     names = ["stage_load issue", "row reads + MFMA S,dP issue", "exp/fma/mul/pack (incl. MFMA drain)",
              "tr reads + MFMA dV,dK issue", "stage_store (incl. vmcnt wait)", "barrier"]
+if MODE == 393:
+    tot = ph[:, :4].sum(axis=1)
+    epi = life - tot - ph[:, 4]
+    print("set-up cycles (median):", np.median(ph[:, 4]), " prologue load wait:", np.median(ph[:, 5]), " prologue total:", np.median(ph[:, 0]),
+          " epilogue (stores drained):", np.median(epi), " lifetime:", np.median(life))
 print("waves:", len(tot), "per 128-query stage:", np.median(tot) / 32, "per 32-query sub-slice:", np.median(tot) / 128)
 for j, nm in enumerate(names):
     print(f"{nm:42s} {100 * np.median(ph[:, j] / tot):5.1f} %   ({np.median(ph[:, j]) / 32:7.1f} cycles per stage)")
