@@ -282,22 +282,48 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
 
 template <typename T, int D, int DIAG = 0>
 int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-                   float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, const Tun& tun = default_tun()) {
+                   float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, const Tun& tun = default_tun(),
+                   const fa::DqPrep* prep = nullptr) {
+  // prep != nullptr: the launch also does the preprocess for its rows and writes the workspace (see dq_fuses_prep)
   const int nqb = (N + 255) / 256;
   lay.rank_chunk = rank_chunk(1, nqb);
   const bool paired = !causal_ranked(tun, batch * nqb, 1);
-  if (DIAG == 0 && causal && N % 256 == 0)   // causal build: unmasked sweep + the diagonal block per wave; one block per workgroup,
+  if (DIAG == 0 && causal && N % 256 == 0) {   // causal build: unmasked sweep + the diagonal block per wave; one block per workgroup,
     // longest first across all heads (paired: blocks p and nqb-1-p in one workgroup)
-    hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), dim3(paired ? batch * ((nqb + 1) / 2) : batch * nqb), dim3(512),
-                       0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau);
-  else if (DIAG == 0 && !causal && N % 128 == 0)   // no sub-tile needs a mask: the build without masked period variants
-    hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
-                       (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
-  else
+    const dim3 grid(paired ? batch * ((nqb + 1) / 2) : batch * nqb);
+    if (prep)
+      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+                         (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, *prep);
+    else
+      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+                         (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, fa::DqPrep{});
+  } else if (DIAG == 0 && !causal && N % 128 == 0) {   // no sub-tile needs a mask: the build without masked period variants
+    if (prep)
+      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, *prep);
+    else
+      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, fa::DqPrep{});
+  } else {
     hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, DIAG>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
+                       (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, fa::DqPrep{});
+  }
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
+}
+
+// bf16, d = 64: does a backward call that asks for the preprocess AND dQ run the dQ slot kernel's builds that fold the preprocess in
+// (dQ is then launched BEFORE dK/dV, which reads the workspace the dQ launch wrote)?  Exactly the launches dq_slot_launch sends to the
+// unmasked / causal builds; option 4 = 1 keeps the separate preprocess kernel (A/B).
+template <typename T, int D>
+bool dq_fuses_prep(int batch, int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    const int need = FA_BWD_STAGE_PREP | FA_BWD_STAGE_DQ;
+    if ((stages & need) != need || tun.v[4] != 0 || (tun.v[2] != 0 && tun.v[2] != 3) || lay.kmask || lay.drop_thr || N < 64) return false;
+    if (causal) return N % 256 == 0 && (tun.v[2] == 3 || batch * (N / 256) >= 128);
+    return N % 128 == 0;
+  }
+  return false;
 }
 
 template <typename T, int D>
@@ -308,10 +334,18 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
   float* nlc = ws;
   float* delta = ws + rows;
   constexpr int RPB = 256 / (D / 8);
-  if (stages & FA_BWD_STAGE_PREP) {
+  const bool fuse_prep = dq_fuses_prep<T, D>(batch, N, lay, causal, stages, tun);
+  if ((stages & FA_BWD_STAGE_PREP) && !fuse_prep) {
     hipLaunchKernelGGL((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
                        (const T*)dout, l, m, nlc, delta, rows, N, lay, variant, 1.0f / tau);
     FA_HIP_TRY(hipGetLastError());
+  }
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    if (fuse_prep) {   // dQ first: it preprocesses its own rows and leaves -L/tau, -delta in the workspace for the dK/dV kernel
+      const fa::DqPrep pa{out, l, m, nlc, delta, variant, 1.0f / tau};
+      const int rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, &pa);
+      if (rc) return rc;
+    }
   }
   if constexpr (sizeof(T) == 2 && D == 64) {
     // One pass for dQ, dK, dV (five products instead of seven): non-causal, N a multiple of 256, all members of a head's
@@ -453,7 +487,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     }
     if (rc) return rc;
   }
-  if (stages & FA_BWD_STAGE_DQ) {
+  if ((stages & FA_BWD_STAGE_DQ) && !fuse_prep) {
     int rc;
     if constexpr (sizeof(T) == 2 && D == 128) {
       if (tun.v[2] == 1)

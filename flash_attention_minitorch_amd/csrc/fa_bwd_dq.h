@@ -230,11 +230,26 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles
 // 0..w and masks the last one; rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p
 // share a workgroup (uniform work).
-template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false>
+// FPREP = true: the launch also does the backward's preprocess (bwd_prep_kernel) for its own query rows: every wave forms
+// -delta = -rowsum(dO * O) and -L / tau of its 32 rows from the forward's O and side outputs (its dO fragments are in registers
+// anyway; the query is on the lane), uses them, and stores them to the workspace, from where the dK/dV kernel, launched AFTER this
+// one, takes them as it always did.  One launch and one pass over dO less per backward (the preprocess kernel: 0.020 ms of the
+// 1.14 ms step at the metric shape).
+struct DqPrep {
+  const float* o;      // forward output, fp32, same layout as q
+  const float* l;      // FA-2: logsumexp; FA-1: sum exp(s - m)
+  const float* m;      // FA-1: row maximum (else unused)
+  float* nlc;          // workspace, written: -L / tau
+  float* ndelta;       // workspace, written: -rowsum(dO * O)
+  int aux_mode;
+  float inv_tau;
+};
+
+template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false, bool FPREP = false>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                    const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
-                   int BH, Layout lay, int causal, float tau) {
+                   int BH, Layout lay, int causal, float tau, DqPrep pa = DqPrep{}) {
   static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
   using A = Atom<T>;
   typedef typename A::frag frag;
@@ -272,8 +287,32 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     qf[kc] = load_frag_buf<T>(qrs, off);
     dof[kc] = load_frag_buf<T>(dors, off);
   }
-  const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
-  const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  float nlq, ndq;
+  if constexpr (FPREP) {   // what bwd_prep_kernel does, for this wave's rows (lanes r and r + 32 hold the two halves of a row's columns)
+    float sum = 0.f, nl = 0.f;
+    if (qvalid) {
+      const float* orow = pa.o + base + (size_t)qrow * ld + 8 * h;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(orow + 16 * kc), b = *reinterpret_cast<const f32x4*>(orow + 16 * kc + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += a[j] * (float)dof[kc][j] + b[j] * (float)dof[kc][4 + j];
+      }
+      const size_t ri = (size_t)bh * N + qrow;
+      const float L = (pa.aux_mode == AUX_FA1) ? (pa.m[ri] + __logf(pa.l[ri])) : pa.l[ri];
+      nl = (L == -INFINITY) ? -INFINITY : -L * pa.inv_tau;
+    }
+    sum = xhalf_sum(sum);
+    if (qvalid && h == 0) {
+      pa.nlc[(size_t)bh * N + qrow] = nl;
+      pa.ndelta[(size_t)bh * N + qrow] = -sum;
+    }
+    nlq = qvalid ? nl * c : 0.f;
+    ndq = qvalid ? -sum : 0.f;
+  } else {
+    nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
+    ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  }
   // -delta enters dP^T as the accumulator input of its MFMA chain (sixteen registers holding one value).  The build with masked
   // periods has no registers for that (it spilled three around the loop): there the VALU adds it, dS = P * (dP + (-delta)).
   constexpr bool NDACC = !MASKS;

@@ -113,7 +113,9 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[1]  forward kernel: 2 = phased, 3 = slot kernel also under the causal mask (whatever the launch size), 6 = 128-key stages
  *   opts[2]  dQ kernel: 1 / 2 / 4 = phased with 64- / 32-key tiles / 4 waves, 3 = slot kernel also under the causal mask
  *   opts[3]  1 = waves 4-7 of the slot kernels run at s_setprio 1
- *   opts[4]  2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
+ *   opts[4]  1 = keep the separate preprocess kernel (default at bf16 d = 64 when the dQ slot kernel runs: the dQ launch preprocesses
+ *            its own rows, writes the workspace and runs BEFORE the dK/dV launch; same results up to summation order of delta);
+ *            2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
  *            head by an ordered hand-off: five products as src/flash_attn2_bw.cu:94-247, no atomics, bitwise reproducible);
  *            bf16, d = 64, non-causal, N a multiple of 256, stages containing both DKDV and DQ; other calls ignore it
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
