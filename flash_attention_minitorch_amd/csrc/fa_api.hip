@@ -258,13 +258,15 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
 
 template <typename T, int D, int BN>
 int dq_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
-              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int only_qb = -1, int care_main = 0) {
+              float* dq, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int only_qb = -1, int care_main = 0,
+              const fa::DqPrep* prep = nullptr) {
+  // prep != nullptr (only when dq_fuses_prep said so: the plain main build runs): the launch also preprocesses its rows
   constexpr bool BF = sizeof(T) == 2;   // CARE policy as fwd_launch_cfg's
   const int nqb = (N + 127) / 128;
   const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);   // causal: query blocks p and nqb-1-p share a workgroup
 #define FA_DQ_LAUNCH(FEAT, CARE, BLOCKS, ONLY)                                                                              \
   hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, FEAT, 4, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q,   \
-                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, ONLY)
+                     (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, ONLY, fa::DqPrep{})
   if (lay.drop_thr) {
     FA_DQ_LAUNCH(2, BF, nblk, only_qb);
   } else if (lay.kmask) {
@@ -272,7 +274,11 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
   } else if (BF && (N < 64 || only_qb >= 0 || (causal && care_main))) {
     FA_DQ_LAUNCH(0, BF, nblk, only_qb);
   } else {
-    FA_DQ_LAUNCH(0, false, nblk, only_qb);
+    if (prep)
+      hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 0, 4, false, true>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
+                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb, *prep);
+    else
+      FA_DQ_LAUNCH(0, false, nblk, only_qb);
     if (BF && causal) FA_DQ_LAUNCH(0, BF, 1, 0);   // rows 0..63 again with split operands
   }
 #undef FA_DQ_LAUNCH
@@ -312,18 +318,74 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
   return FA_OK;
 }
 
-// bf16, d = 64: does a backward call that asks for the preprocess AND dQ run the dQ slot kernel's builds that fold the preprocess in
-// (dQ is then launched BEFORE dK/dV, which reads the workspace the dQ launch wrote)?  Exactly the launches dq_slot_launch sends to the
-// unmasked / causal builds; option 4 = 1 keeps the separate preprocess kernel (A/B).
+// Does a backward call that asks for the preprocess AND dQ fold the preprocess into its dQ launch (dQ is then launched BEFORE dK/dV,
+// which reads the workspace the dQ launch wrote)?  Yes whenever dq_stage sends the call to a plain main build: not under a key mask
+// or dropout, not bf16 with N < 64 (split-operand builds), not the bf16 d = 64 slot build with masked periods (no registers), not a
+// diagnostic build; option 4 = 1 keeps the separate preprocess kernel (A/B), 2 is the one-pass backward.
 template <typename T, int D>
 bool dq_fuses_prep(int batch, int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
-  if constexpr (sizeof(T) == 2 && D == 64) {
-    const int need = FA_BWD_STAGE_PREP | FA_BWD_STAGE_DQ;
-    if ((stages & need) != need || tun.v[4] != 0 || (tun.v[2] != 0 && tun.v[2] != 3) || lay.kmask || lay.drop_thr || N < 64) return false;
-    if (causal) return N % 256 == 0 && (tun.v[2] == 3 || batch * (N / 256) >= 128);
-    return N % 128 == 0;
+  constexpr bool BF = sizeof(T) == 2;
+  const int need = FA_BWD_STAGE_PREP | FA_BWD_STAGE_DQ;
+  if ((stages & need) != need || tun.v[4] != 0 || lay.kmask || lay.drop_thr || (BF && N < 64) || tun.v[2] > 4) return false;
+  if constexpr (BF && D == 64) {
+    const bool phased = tun.v[2] == 1 || tun.v[2] == 2 || (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * (N / 256) >= 128));
+    if (!phased) return causal ? N % 256 == 0 : N % 128 == 0;   // the slot kernel: its unmasked / causal builds only
   }
-  return false;
+  return true;
+}
+
+// The dQ stage of a backward call: kernel selection by dtype / head dim / launch shape / options.  prep != nullptr: the launch also does
+// the preprocess for its rows (dq_fuses_prep decided that a plain main build runs).
+template <typename T, int D>
+int dq_stage(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta, float* dq, int batch,
+             int N, fa::Layout lay, int causal, float tau, hipStream_t st, const Tun& tun, const fa::DqPrep* prep) {
+  int rc;
+  if constexpr (sizeof(T) == 2 && D == 128) {
+    if (tun.v[2] == 1)
+      rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+    else if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr || N < 64)   // 4 waves x 32 queries, two workgroups per CU
+      rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+    else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
+      const int nqb = (N + 255) / 256;
+      if (prep)
+        hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, 32, 0, 8, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, *prep);
+      else
+        hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, fa::DqPrep{});
+      FA_HIP_TRY(hipGetLastError());
+      rc = FA_OK;
+    }
+  } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
+    if (tun.v[2] == 1)
+      rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+    else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || N < 64 ||
+             (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * (N / 256) >= 128)))
+      // key mask and dropout live in the phased kernel, which is also 1 % faster than the slot build WITH masked periods under
+      // the causal mask (tuning key 2 = 3 forces the slot kernel).  Causal launches with N a multiple of 256 take the causal slot
+      // build (unmasked sweep + diagonal block per wave, paired query blocks): 0.199 vs 0.223 ms at the metric shape
+      rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+#ifdef FA_DIAG
+    else if (tun.v[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
+      rc = dq_slot_launch<T, D, 2>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+    else if (tun.v[2] == 93)   // phase stamps (never timed)
+      rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
+#endif
+    else {
+      rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, prep);
+      // the masked slot build forced onto a causal launch: rows 0..63 (few keys) are redone by the phased kernel's split-operand
+      // path (query block 0); the causal slot build (N a multiple of 256) splits them itself
+      if (!rc && causal && N % 256 != 0) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);
+    }
+  } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
+    if (tun.v[2] == 1)
+      rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+    else
+      rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+  } else {
+    rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep);
+  }
+  return rc;
 }
 
 template <typename T, int D>
@@ -340,12 +402,10 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
                        (const T*)dout, l, m, nlc, delta, rows, N, lay, variant, 1.0f / tau);
     FA_HIP_TRY(hipGetLastError());
   }
-  if constexpr (sizeof(T) == 2 && D == 64) {
-    if (fuse_prep) {   // dQ first: it preprocesses its own rows and leaves -L/tau, -delta in the workspace for the dK/dV kernel
-      const fa::DqPrep pa{out, l, m, nlc, delta, variant, 1.0f / tau};
-      const int rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, &pa);
-      if (rc) return rc;
-    }
+  if (fuse_prep) {   // dQ first: it preprocesses its own rows and leaves -L/tau, -delta in the workspace for the dK/dV kernel
+    const fa::DqPrep pa{out, l, m, nlc, delta, variant, 1.0f / tau};
+    const int rc = dq_stage<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, &pa);
+    if (rc) return rc;
   }
   if constexpr (sizeof(T) == 2 && D == 64) {
     // One pass for dQ, dK, dV (five products instead of seven): non-causal, N a multiple of 256, all members of a head's
@@ -488,48 +548,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     if (rc) return rc;
   }
   if ((stages & FA_BWD_STAGE_DQ) && !fuse_prep) {
-    int rc;
-    if constexpr (sizeof(T) == 2 && D == 128) {
-      if (tun.v[2] == 1)
-        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr || N < 64)   // 4 waves x 32 queries, two workgroups per CU
-        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
-        const int nqb = (N + 255) / 256;
-        hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
-                           (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau);
-        FA_HIP_TRY(hipGetLastError());
-        rc = FA_OK;
-      }
-    } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
-      if (tun.v[2] == 1)
-        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || N < 64 ||
-               (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * (N / 256) >= 128)))
-        // key mask and dropout live in the phased kernel, which is also 1 % faster than the slot build WITH masked periods under
-        // the causal mask (tuning key 2 = 3 forces the slot kernel).  Causal launches with N a multiple of 256 take the causal slot
-        // build (unmasked sweep + diagonal block per wave, paired query blocks): 0.199 vs 0.223 ms at the metric shape
-        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-#ifdef FA_DIAG
-      else if (tun.v[2] == 94)   // timing ablation: no per-stage barrier (WRONG results; upper bound for a flag-based hand-off)
-        rc = dq_slot_launch<T, D, 2>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else if (tun.v[2] == 93)   // phase stamps (never timed)
-        rc = dq_slot_launch<T, D, 1>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-#endif
-      else {
-        rc = dq_slot_launch<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun);
-        // the masked slot build forced onto a causal launch: rows 0..63 (few keys) are redone by the phased kernel's split-operand
-        // path (query block 0); the causal slot build (N a multiple of 256) splits them itself
-        if (!rc && causal && N % 256 != 0) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);
-      }
-    } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
-      if (tun.v[2] == 1)
-        rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-      else
-        rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-    } else {
-      rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st);
-    }
+    const int rc = dq_stage<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, nullptr);
     if (rc) return rc;
   }
   return FA_OK;

@@ -5,15 +5,58 @@
 
 namespace fa {
 
+// FPREP = true (both dQ kernels): the launch also does the backward's preprocess (bwd_prep_kernel) for its own query rows: every wave forms
+// -delta = -rowsum(dO * O) and -L / tau of its 32 rows from the forward's O and side outputs (its dO fragments are in registers
+// anyway; the query is on the lane), uses them, and stores them to the workspace, from where the dK/dV kernel, launched AFTER this
+// one, takes them as it always did.  One launch and one pass over dO less per backward (the preprocess kernel: 0.020 ms of the
+// 1.14 ms step at the metric shape).
+struct DqPrep {
+  const float* o;      // forward output, fp32, same layout as q
+  const float* l;      // FA-2: logsumexp; FA-1: sum exp(s - m)
+  const float* m;      // FA-1: row maximum (else unused)
+  float* nlc;          // workspace, written: -L / tau
+  float* ndelta;       // workspace, written: -rowsum(dO * O)
+  int aux_mode;
+  float inv_tau;
+};
+// What bwd_prep_kernel does, for one wave's 32 query rows (the query is on the lane; lanes r and r + 32 hold the two halves of each
+// 16-column chunk of the row, dof = this lane's dO fragments): forms -L/tau and -delta, stores them, returns the lane's constants.
+template <typename T, int KC>
+FA_DEV void dq_prep_rows(const DqPrep& pa, const typename Atom<T>::frag (&dof)[KC], size_t base, int bh, int N, int qrow, int ld, int h,
+                         bool qvalid, float c, float& nlq, float& ndq) {
+  float sum = 0.f, nl = 0.f;
+  if (qvalid) {
+    const float* orow = pa.o + base + (size_t)qrow * ld + 8 * h;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(orow + 16 * kc), b = *reinterpret_cast<const f32x4*>(orow + 16 * kc + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum += a[j] * (float)dof[kc][j] + b[j] * (float)dof[kc][4 + j];
+    }
+    const size_t ri = (size_t)bh * N + qrow;
+    const float L = (pa.aux_mode == AUX_FA1) ? (pa.m[ri] + __logf(pa.l[ri])) : pa.l[ri];
+    nl = (L == -INFINITY) ? -INFINITY : -L * pa.inv_tau;
+  }
+  sum = xhalf_sum(sum);
+  if (qvalid && h == 0) {
+    pa.nlc[(size_t)bh * N + qrow] = nl;
+    pa.ndelta[(size_t)bh * N + qrow] = -sum;
+  }
+  nlq = qvalid ? nl * c : 0.f;
+  ndq = qvalid ? -sum : 0.f;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Backward dQ: same shape as the forward (NWQ waves x 32 query rows, K/V tiles of BN keys through LDS).  NWQ = 4 by
 // default; the bf16 d = 128 launch uses 8 (one workgroup per CU sharing each staged tile between twice the waves).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4, bool CARE = false>   // CARE: as fwd_kernel's
+template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4, bool CARE = false, bool FPREP = false>   // CARE: as fwd_kernel's
 __global__ void __launch_bounds__(64 * NWQ)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
-              int BH, Layout lay, int causal, float tau, int only_qb = -1) {
+              int BH, Layout lay, int causal, float tau, int only_qb = -1, DqPrep pa = DqPrep{}) {
+  static_assert(!FPREP || (FEAT == 0 && !CARE), "the preprocess is folded into the plain main build only");
   using A = Atom<T>;   // only_qb: as fwd_kernel's
   typedef typename A::frag frag;
   constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
@@ -52,8 +95,13 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
     dof[kc] = load_frag_buf<T>(dors, off);
   }
   // this lane's row constants; -delta, in every register, is the accumulator input of the dP^T tiles
-  const float nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
-  const float ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  float nlq, ndq;
+  if constexpr (FPREP) {
+    dq_prep_rows<T, KC>(pa, dof, base, bh, N, qrow, ld, h, qvalid, c, nlq, ndq);
+  } else {
+    nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
+    ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
+  }
   f32x16 nd16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) nd16[i] = ndq;
@@ -230,21 +278,6 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles
 // 0..w and masks the last one; rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p
 // share a workgroup (uniform work).
-// FPREP = true: the launch also does the backward's preprocess (bwd_prep_kernel) for its own query rows: every wave forms
-// -delta = -rowsum(dO * O) and -L / tau of its 32 rows from the forward's O and side outputs (its dO fragments are in registers
-// anyway; the query is on the lane), uses them, and stores them to the workspace, from where the dK/dV kernel, launched AFTER this
-// one, takes them as it always did.  One launch and one pass over dO less per backward (the preprocess kernel: 0.020 ms of the
-// 1.14 ms step at the metric shape).
-struct DqPrep {
-  const float* o;      // forward output, fp32, same layout as q
-  const float* l;      // FA-2: logsumexp; FA-1: sum exp(s - m)
-  const float* m;      // FA-1: row maximum (else unused)
-  float* nlc;          // workspace, written: -L / tau
-  float* ndelta;       // workspace, written: -rowsum(dO * O)
-  int aux_mode;
-  float inv_tau;
-};
-
 template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false, bool FPREP = false>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
@@ -288,27 +321,8 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     dof[kc] = load_frag_buf<T>(dors, off);
   }
   float nlq, ndq;
-  if constexpr (FPREP) {   // what bwd_prep_kernel does, for this wave's rows (lanes r and r + 32 hold the two halves of a row's columns)
-    float sum = 0.f, nl = 0.f;
-    if (qvalid) {
-      const float* orow = pa.o + base + (size_t)qrow * ld + 8 * h;
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(orow + 16 * kc), b = *reinterpret_cast<const f32x4*>(orow + 16 * kc + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum += a[j] * (float)dof[kc][j] + b[j] * (float)dof[kc][4 + j];
-      }
-      const size_t ri = (size_t)bh * N + qrow;
-      const float L = (pa.aux_mode == AUX_FA1) ? (pa.m[ri] + __logf(pa.l[ri])) : pa.l[ri];
-      nl = (L == -INFINITY) ? -INFINITY : -L * pa.inv_tau;
-    }
-    sum = xhalf_sum(sum);
-    if (qvalid && h == 0) {
-      pa.nlc[(size_t)bh * N + qrow] = nl;
-      pa.ndelta[(size_t)bh * N + qrow] = -sum;
-    }
-    nlq = qvalid ? nl * c : 0.f;
-    ndq = qvalid ? -sum : 0.f;
+  if constexpr (FPREP) {
+    dq_prep_rows<T, KC>(pa, dof, base, bh, N, qrow, ld, h, qvalid, c, nlq, ndq);
   } else {
     nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
     ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
