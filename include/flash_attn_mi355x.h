@@ -95,8 +95,11 @@ int fa_mi355x_bwd(const void* q, const void* k, const void* v, const float* out,
                   float* q_grad, float* k_grad, float* v_grad, const float* l, const float* m,
                   void* workspace, int batch, int N, int d, int causal, int variant, int dtype, void* stream);
 
-/* The same, restricted to some of its three kernels (bench.py times them one by one; stages run in the order
- * prep -> dK/dV -> dQ and the later two need prep's workspace contents). */
+/* The same, restricted to some of its stages (bench.py times them one by one).  dK/dV and dQ need the workspace contents that the
+ * PREP stage leaves (-L/tau and -rowsum(dO*O) per row).  A call that asks for PREP and DQ together runs them as ONE launch wherever a
+ * plain dQ kernel is selected (no key mask / dropout, bf16 with N >= 64, ...): the dQ kernel preprocesses its own rows, writes the
+ * workspace and runs first, dK/dV (if asked for) after it; otherwise the order is prep kernel -> dK/dV -> dQ.  The workspace
+ * contents are the same either way (up to the summation order of delta). */
 #define FA_BWD_STAGE_PREP 1     /* workspace <- -L/tau, -rowsum(dO*O) */
 #define FA_BWD_STAGE_DKDV 2     /* k_grad, v_grad */
 #define FA_BWD_STAGE_DQ   4     /* q_grad */
