@@ -800,6 +800,30 @@ def test_bnhd_layout_matches_permuted_copy(dev, dtype, causal, N):
             assert maxabs(f(a).reshape(B * H, N, d), ref[nm]) < tol, nm
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_bnhd_layout_at_chip_filling_size(dev, causal):
+    """[B][N][H][d] in place at a launch size that takes the builds small launches never reach: the tiled dK/dV kernel (key block kb of
+    consecutive heads per workgroup: the next head sits H*d elements further, not N*d) and, under the causal mask, the causal slot
+    builds with ranked block order.  Bit-identical to the [B*H][N][d] path on permuted copies; four heads against the oracle."""
+    import torch
+    torch.manual_seed(5)
+    B, H, N, d = 32, 8, 512, 64
+    q, k, v, do = (((torch.rand((B, N, H, d), device="cuda") - 0.5) * 2).to(torch.bfloat16) for _ in range(4))
+    perm = lambda t: t.permute(0, 2, 1, 3).contiguous()
+    o, l, m = dev.flash_attn_fwd_bnhd(q, k, v, causal)
+    dq, dk, dv = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal)
+    o_r, l_r, m_r = dev.flash_attn_fwd(perm(q), perm(k), perm(v), causal)
+    g_r = dev.flash_attn_bwd(perm(q), perm(k), perm(v), o_r, perm(do), l_r, m_r, causal)
+    assert torch.equal(perm(o), o_r) and torch.equal(l, l_r)
+    for a, b in zip((dq, dk, dv), g_r):
+        assert torch.equal(perm(a), b)
+    heads = [0, 7, 100, B * H - 1]
+    f = lambda t: to_np(perm(t).float()).reshape(B * H, N, d)
+    ref = oracle_heads(f(q), f(k), f(v), f(do), causal, heads)
+    for nm, a in (("o", o), ("dq", dq), ("dk", dk), ("dv", dv)):
+        assert maxabs(f(a)[heads], ref[nm]) < TOLBF, nm
+
+
 def test_autograd_functions_follow_reference_contract(dev):
     """Flash_Attn / Flash_Attn2 / Flash_Attn_Causal: forward returns o, backward yields one grad per tensor input
     (minitorch/tensor_functions.py:462-497)."""
