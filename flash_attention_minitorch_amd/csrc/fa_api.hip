@@ -150,7 +150,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
       if (whole && tun.v[1] == 93 && D == 64) {   // phase stamps (never timed)
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 1>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 1, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;

@@ -574,8 +574,11 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     } else {
       // two sub-tiles per stage: stage st+1 (requested one stage ago) is published here, then stage st+2 is requested
       if (st > 0) {   // (stage 1 was waited for and published in the prologue)
+        if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
         dma_wait_all();
+        if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
         __syncthreads();
+        if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
       }
       if (CDIAG || st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));   // (causal build: the diagonal block follows)
       // period 2st+0: produce sub 1, softmax of sub 0, P.V of sub 1 of the previous stage; rows two ahead: next stage, sub 0

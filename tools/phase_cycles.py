@@ -56,6 +56,6 @@ if MODE == 393:
     epi = life - tot - ph[:, 4]
     print("set-up cycles (median):", np.median(ph[:, 4]), " prologue load wait:", np.median(ph[:, 5]), " prologue total:", np.median(ph[:, 0]),
           " epilogue (stores drained):", np.median(epi), " lifetime:", np.median(life))
-print("waves:", len(tot), "per 128-query stage:", np.median(tot) / 32, "per 32-query sub-slice:", np.median(tot) / 128)
+print("waves:", len(tot), "per 128-row stage:", np.median(tot) / 32, "per 32-query sub-slice:", np.median(tot) / 128)
 for j, nm in enumerate(names):
     print(f"{nm:42s} {100 * np.median(ph[:, j] / tot):5.1f} %   ({np.median(ph[:, j]) / 32:7.1f} cycles per stage)")
