@@ -369,7 +369,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   };
   auto slot_of = [&](int st) { return (st % R) * TB; };
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, k_t0 = 0, k_r0 = 0, t0 = 0, t1 = 0;
-  if constexpr (DIAG) {
+  if constexpr (DIAG == 1) {
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
   }
@@ -384,7 +384,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   if (NSUBT == 2 && nstage > 1) stage_dma(ST, slot_of(1));
   dma_wait_all();
   __syncthreads();
-  if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
+  if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
   if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
   f32x16 sA, sB;
@@ -552,11 +552,11 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       } else {
         period(T1, T1, T1, T0, ic<2>{}, ic<0>{}, ic<3>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, kb + 32, sA, sB, pA0, pA1, pB0, pB1);
       }
-      if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
+      if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; }
       dma_wait_all();   // this wave's pieces of the next stage have landed
-      if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
+      if constexpr (DIAG == 1) { t0 = stamp(); ph[2] += t0 - t1; }
       __syncthreads();
-      if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+      if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
       // period 4st+2: produce sub 3, softmax of sub 2, P.V of sub 1; rows two ahead = sub 0 of the next stage
       if constexpr (MASKS) {
         if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, ic<2>{}, cr0, cr1, ct0, ct1, nr0, nr1, cr0, cr1, kb + 64, sB, sA, pB0, pB1, pA0, pA1);
@@ -574,11 +574,11 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     } else {
       // two sub-tiles per stage: stage st+1 (requested one stage ago) is published here, then stage st+2 is requested
       if (st > 0) {   // (stage 1 was waited for and published in the prologue)
-        if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; }
+        if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; }
         dma_wait_all();
-        if constexpr (DIAG) { t0 = stamp(); ph[2] += t0 - t1; }
-        __syncthreads();
-        if constexpr (DIAG) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
+        if constexpr (DIAG == 1) { t0 = stamp(); ph[2] += t0 - t1; }
+        if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
+        if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
       }
       if (CDIAG || st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));   // (causal build: the diagonal block follows)
       // period 2st+0: produce sub 1, softmax of sub 0, P.V of sub 1 of the previous stage; rows two ahead: next stage, sub 0
@@ -681,7 +681,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     for (int j = 4; j <= w; ++j) diag_tile(j, false);
   }
 
-  if constexpr (DIAG) { t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
+  if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
   const float l_tot = xhalf_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (qvalid) {
@@ -696,7 +696,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       }
     if (h == 0) aux_l[(size_t)bh * N + qrow] = m_ref * tau + __logf(l_tot);
   }
-  if constexpr (DIAG) {
+  if constexpr (DIAG == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long k_t1 = stamp(), k_r1 = __builtin_amdgcn_s_memrealtime();
     ph[4] += k_t1 - t0;   // epilogue: O / L stores
