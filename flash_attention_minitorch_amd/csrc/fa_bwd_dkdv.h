@@ -67,7 +67,10 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh, pblk;
-  map_block(blockIdx.x, BH, thin_mode == 2 ? 1 : (PAIR ? (nkb + 1) / 2 : nkb), bh, pblk);
+  // (unpaired causal launches: key block 0 sweeps the most query stages; with lay.rank_chunk set the blocks are dispatched longest
+  // first across a chunk of heads instead of head by head, cf. map_block_ranked)
+  if (!PAIR && thin_mode != 2 && causal && lay.rank_chunk > 0) map_block_ranked(blockIdx.x, BH, nkb, lay.rank_chunk, bh, pblk);
+  else map_block(blockIdx.x, BH, thin_mode == 2 ? 1 : (PAIR ? (nkb + 1) / 2 : nkb), bh, pblk);
   const int npass = (PAIR && pblk != nkb - 1 - pblk) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   const int kb = (PAIR && pass == 1) ? nkb - 1 - pblk : pblk;

@@ -69,10 +69,13 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // causal launches pair query block p with block nqb-1-p in one workgroup (see fwd_kernel): uniform work per workgroup
-  const int nblk = only_qb >= 0 ? 1 : (causal ? (nqb + 1) / 2 : nqb);
+  // ... or, with lay.rank_chunk set, one block per workgroup dispatched longest first across a chunk of heads (map_block_ranked)
+  const bool ranked = only_qb < 0 && causal && lay.rank_chunk > 0;
+  const int nblk = only_qb >= 0 ? 1 : ((causal && !ranked) ? (nqb + 1) / 2 : nqb);
   int bh, pblk;
-  map_block(blockIdx.x, BH, nblk, bh, pblk);
-  const int npass = (only_qb < 0 && causal && pblk != nqb - 1 - pblk) ? 2 : 1;
+  if (ranked) map_block_ranked(blockIdx.x, BH, nblk, lay.rank_chunk, bh, pblk);
+  else map_block(blockIdx.x, BH, nblk, bh, pblk);
+  const int npass = (only_qb < 0 && causal && !ranked && pblk != nqb - 1 - pblk) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   const int qb = only_qb >= 0 ? only_qb : (causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk);
   const int q0 = qb * (32 * NWQ) + w * 32, qrow = q0 + r;

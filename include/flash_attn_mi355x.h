@@ -125,8 +125,10 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *            per workgroup when the launch still covers every CU; bitwise the same results)
  *   opts[6]  1 = causal bf16 d = 64 forward and dK/dV (phased kernels): main kernels + small follow-up launches for the rows with few
  *            keys instead of the single split-operand build (A/B; same results)
- *   opts[7]  causal builds of the forward / dQ slot kernels: 1 = query blocks p and nqb-1-p paired in one workgroup, 2 = one block
- *            per workgroup dispatched longest first; 0 = by launch size (ranked below 8 rounds of the chip)
+ *   opts[7]  block order of causal launches: 1 = query blocks p and nqb-1-p paired in one workgroup (slot and phased forward / dQ
+ *            kernels) and head-by-head order for the unpaired dK/dV launches (fp32 d = 64, bf16 d = 128); 2 = one block per
+ *            workgroup dispatched longest first across a chunk of heads, everywhere; 0 = per kernel what measured faster (slot
+ *            builds: ranked below 8 rounds of the chip; phased forward / dQ: paired; unpaired dK/dV: ranked)
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
  * library (FA_ERR_BAD_ARG).  `stages` as fa_mi355x_bwd_stages. */
 int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
