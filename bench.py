@@ -303,10 +303,10 @@ def main():
     K_DKDV = "bwd_dkdv_slot_kernel" if (bf and d == 64) or (cslot and cblocks >= 128) else "bwd_dkdv_kernel"
     STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
               (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
-    # bf16, d = 64 on the dQ slot kernel: the dQ launch preprocesses its own rows and runs BEFORE dK/dV (no preprocess kernel; what
-    # fa_mi355x_bwd does in one call: fa_api.hip, dq_fuses_prep)
-    fuse_prep = K_DQ == "bwd_dq_slot_kernel" and (OPTS is None or len(OPTS) < 5 or OPTS[4] == 0) and \
-        ((not causal and N % 128 == 0) or (causal and N % 256 == 0))
+    # The dQ launch preprocesses its own rows and runs BEFORE dK/dV (no preprocess kernel): what fa_mi355x_bwd does in one call, and
+    # the same rule as fa_api.hip's dq_fuses_prep (every plain dQ build folds the preprocess in; the masked d = 64 slot build does not)
+    fuse_prep = (OPTS is None or len(OPTS) < 5 or OPTS[4] == 0) and (args.dtype != "bf16" or N >= 64) and \
+        (K_DQ != "bwd_dq_slot_kernel" or (not causal and N % 128 == 0) or (causal and N % 256 == 0))
     if fuse_prep:
         STAGES = ((K_FWD, fwd), (K_DQ, lambda: bwd(device_ops.STAGE_PREP | device_ops.STAGE_DQ)),
                   (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)))
