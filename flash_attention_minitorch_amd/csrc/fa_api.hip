@@ -222,9 +222,12 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 4, 64, 1, HD, 1, BF>), dim3(GRID), dim3(256), 0, st, (const T*)q, (const T*)k, \
                      (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb4, batch, lay, causal, tau, THIN)
   if (lay.drop_thr) {   // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key)
+    // (these whole-launch builds take one key block per workgroup: under the causal mask longest first across a chunk of heads)
     if constexpr (BF) {
+      if (causal && rank_causal) lay.rank_chunk = rank_chunk(2, nkb4);
       FA_CARE_LAUNCH(true, batch * nkb4, 0);
     } else {
+      if (causal && rank_causal) lay.rank_chunk = rank_chunk(2, nkb);
       hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
                          (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
                          causal, tau, 0);
@@ -234,6 +237,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   }
   if constexpr (BF) {
     if (lay.kmask || N < 64) {
+      if (causal && rank_causal) lay.rank_chunk = rank_chunk(2, nkb4);
       FA_CARE_LAUNCH(false, batch * nkb4, 0);
       FA_HIP_TRY(hipGetLastError());
       return FA_OK;
