@@ -397,6 +397,32 @@ def test_tiled_dkdv_build_is_bitwise_the_one_head_build(dev, BH, N):
         assert maxabs(got[heads], ref[nm]) < TOLBF, (nm, maxabs(got[heads], ref[nm]))
 
 
+@pytest.mark.parametrize("BH,N", [(127, 256), (128, 256), (255, 256), (256, 256), (64, 512), (63, 512), (32, 1024), (257, 256)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_default_dispatch_around_launch_size_thresholds(dev, BH, N, causal):
+    """bf16, d = 64, default options: the launcher picks slot / phased, tiled / one-head, ranked / paired builds and the folded
+    preprocess by launch size (128 / 256 blocks, one workgroup per CU per head group, batch*head a multiple of 8 or not).  Shapes on
+    both sides of each threshold: every head against the phased kernels with the separate preprocess kernel (options (4, 2, 2, 0, 1):
+    same arithmetic per element), first and last head against the oracle."""
+    import torch
+    rng = np.random.default_rng(9300 + BH + N)
+    d = 64
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    outs = {}
+    for tag, opts in (("default", None), ("phased", (4, 2, 2, 0, 1))):
+        o, l, _ = dev.flash_attn_fwd(tq, tk, tv, causal=causal, opts=opts)
+        dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, None, causal=causal, opts=opts)
+        outs[tag] = [to_np(x) for x in (o, l, dq, dk, dv)]
+    for nm, a, b in zip(("o", "L", "dq", "dk", "dv"), outs["default"], outs["phased"]):
+        assert np.all(np.isfinite(a)), nm
+        assert maxabs(a, b) < TOLBF, (nm, maxabs(a, b))
+    heads = [0, BH - 1]
+    ref = oracle_heads(*arrs, causal, heads)
+    for nm, got in zip(("o", "L", "dq", "dk", "dv"), outs["default"]):
+        assert maxabs(got[heads], ref[nm]) < TOLBF, (nm, maxabs(got[heads], ref[nm]))
+
+
 @pytest.mark.parametrize("BH,N", [(24, 512), (5, 768), (40, 256), (16, 2560), (72, 1024)])
 @pytest.mark.parametrize("order", [1, 2])
 def test_causal_slot_builds_block_order(dev, BH, N, order):
