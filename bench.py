@@ -67,7 +67,29 @@ def parse():
     return ap.parse_args()
 
 
-def run_extras(torch, device_ops, q, k, v, do, causal):
+def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd):
+    """The step as a list of (kernel name, callable) in the library's own launch order, from fa_mi355x_plan.  A backward plan without
+    bwd_prep_kernel means the dQ launch preprocesses its own rows and runs first; bwd_fused_kernel is the opt-in one-pass backward."""
+    from flash_attention_minitorch_amd import _lib
+    dt = _lib.FA_DTYPE_BF16 if dtype == "bf16" else _lib.FA_DTYPE_F32
+    plan = lambda stages: _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, stages, opts)
+    main = lambda names: [n for n in names if n != "bwd_prep_kernel"][0]   # (a follow-up launch of the same kernel follows its main one)
+    k_fwd = main(plan(0))
+    whole = plan(device_ops.STAGE_ALL)
+    k_dq, k_dkdv = main(plan(device_ops.STAGE_DQ)), main(plan(device_ops.STAGE_DKDV))
+    if "bwd_fused_kernel" in whole:
+        stages = ((k_fwd, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
+                  ("bwd_fused_kernel", lambda: bwd(device_ops.STAGE_DKDV | device_ops.STAGE_DQ)))
+    elif "bwd_prep_kernel" in whole:
+        stages = ((k_fwd, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
+                  (k_dkdv, lambda: bwd(device_ops.STAGE_DKDV)), (k_dq, lambda: bwd(device_ops.STAGE_DQ)))
+    else:
+        stages = ((k_fwd, fwd), (k_dq, lambda: bwd(device_ops.STAGE_PREP | device_ops.STAGE_DQ)),
+                  (k_dkdv, lambda: bwd(device_ops.STAGE_DKDV)))
+    return stages, k_fwd, k_dq, k_dkdv
+
+
+def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
     """vs_vanilla at the bench shape and the per-variant [total, fw, bw] table; a few seconds, after the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import vanilla_gpu as vg
@@ -92,6 +114,15 @@ def run_extras(torch, device_ops, q, k, v, do, causal):
     r["speedup_fw"] = r["vanilla_fw_ms"] / r["flash_fw_ms"]
     r["speedup_fwbw"] = r["vanilla_fwbw_ms"] / r["flash_fwbw_ms"]
     r["vanilla"] = "torch-ROCm materialised S: bf16 matmuls (hipBLASLt), fp32 softmax, autograd backward; device resident"
+    # the reference's SECOND comparator (minitorch/modules_transfomer.py:131-136, use_fused_kernel): the same materialised scores, but
+    # mask + softmax as ONE fused kernel (src/softmax_kernel.cu:236-282 with its [B, 1, 1, N] padding mask, all zeros there)
+    q4, k4, v4, do4 = (t.view(B, H, N, d) for t in (q, k, v, do))
+    f_fw2 = lambda: vg.fused_softmax_attention(q4, k4, v4, causal)
+    f_fwbw2 = lambda: vg.fused_softmax_fw_bw(q4, k4, v4, do4, causal)
+    r["fused_softmax_fw_ms"], r["fused_softmax_fwbw_ms"] = vg.time_ms(f_fw2, 3), vg.time_ms(f_fwbw2, 3)
+    r["speedup_fw_vs_fused_softmax"] = r["fused_softmax_fw_ms"] / r["flash_fw_ms"]
+    r["speedup_fwbw_vs_fused_softmax"] = r["fused_softmax_fwbw_ms"] / r["flash_fwbw_ms"]
+    r["fused_softmax"] = "the same with mask + softmax as one fused kernel (" + vg.fused_softmax_kind() + "): the reference's attn_softmax path"
     out["vs_vanilla"] = {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in r.items()}
     torch.cuda.empty_cache()
     # --- the reference's "breakup" figure (kernel_tests/test_flashattn_breakdown.py:44-66: B=8 H=8 d=64 fp32, causal mask on):
@@ -108,7 +139,16 @@ def run_extras(torch, device_ops, q, k, v, do, causal):
     torch.cuda.empty_cache()
 
     # --- per-variant [total, fw, bw]
-    def three(B, H, N_, d_, tdt, variant, caus):
+    def fw_only(BH_, N_, d_):   # [ms, TFLOP/s, fraction of the 2.5 PFLOP/s dense bf16 peak] of one forward launch
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        mk = lambda: ((torch.rand((BH_, N_, d_), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
+        qq, kk, vv = mk(), mk(), mk()
+        oo, ll, _ = device_ops.flash_attn_fwd(qq, kk, vv, False)
+        tf = vg.time_ms(lambda: device_ops.flash_attn_fwd(qq, kk, vv, False, out=oo, l=ll), 20, 5)
+        tfl = 4.0 * BH_ * N_ * N_ * d_ / tf / 1e9
+        return {"ms_tflops_frac": [round(tf, 4), round(tfl, 1), round(tfl / PEAK_BF16_TFLOPS, 4)]}
+
+    def three(B, H, N_, d_, tdt, variant, caus, iters=10, warm=3):
         gen = torch.Generator(device="cuda").manual_seed(7)
         mk = lambda: ((torch.rand((B * H, N_, d_), device="cuda", generator=gen) - 0.5) * 2).to(tdt)
         qq, kk, vv, dd = mk(), mk(), mk(), mk()
@@ -117,7 +157,7 @@ def run_extras(torch, device_ops, q, k, v, do, causal):
         gg = tuple(torch.empty(qq.shape, dtype=torch.float32, device="cuda") for _ in range(3))
         fw = lambda: device_ops.flash_attn_fwd(qq, kk, vv, caus, variant, out=oo, l=ll, m=mm)
         bw = lambda: device_ops.flash_attn_bwd(qq, kk, vv, oo, dd, ll, mm, caus, variant, workspace=w2, grads=gg)
-        tf, tb = vg.time_ms(fw, 10, 3), vg.time_ms(bw, 10, 3)
+        tf, tb = vg.time_ms(fw, iters, warm), vg.time_ms(bw, iters, warm)
         cf = 0.5 if caus else 1.0
         fl_fw, fl_bw = 4.0 * B * H * N_ * N_ * d_ * cf, 10.0 * B * H * N_ * N_ * d_ * cf
         return {"ms_total_fw_bw": [round(tf + tb, 4), round(tf, 4), round(tb, 4)],
@@ -135,7 +175,18 @@ def run_extras(torch, device_ops, q, k, v, do, causal):
         "configs[2] FA-1 fp32 B8 H8 N2048 d64": three(8, 8, 2048, 64, f32, FA1, False),
         "configs[3] FA-2 bf16 B16 H16 N4096 d128": three(16, 16, 4096, 128, bf, FA2, False),
         "metric shape causal FA-2 bf16 B8 H8 N4096 d64": three(8, 8, 4096, 64, bf, FA2, True),
+        "configs[4] per-rank slice: FA-2 fw bf16 BH=256 N=4096 d=128": fw_only(256, 4096, 128),
     }
+    torch.cuda.empty_cache()
+    # --- the reference's ablation sweep (README.md:12-13, kernel_tests/test_flashattn_time.py:96-102: batch, heads, head dim; "batch
+    # and head are equivalent"): FA-2 fw+bw TFLOP/s, bf16, N = 2048, non-causal, device resident
+    abl = {"what": "FA-2 fw+bw TFLOP/s (14*B*H*N^2*d flops), bf16 in / fp32 out, N=2048, non-causal; key = B<batch>H<heads>d<head dim>"}
+    for dd in (32, 64, 128):
+        for BB in (4, 8, 16):
+            for HH in (4, 8, 16):
+                r3 = three(BB, HH, 2048, dd, bf, FA2, False, iters=4, warm=2)
+                abl[f"B{BB}H{HH}d{dd}"] = r3["tflops_total_fw_bw"][0]
+    out["ablation"] = abl
     return out
 
 
@@ -291,29 +342,11 @@ def main():
     def bwd(stages=device_ops.STAGE_ALL):
         device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages, opts=OPTS)
 
-    # One step = forward + backward; the backward's three kernels are launched one by one so that a HIP event can
-    # be recorded between kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).
-    # kernel names as rocprofv3 shows them (fa::<name><...>): bf16 d=64 runs the slot-interleaved forward / dQ kernels
-    bf = args.dtype == "bf16" and not causal and not args.phased
-    # causal, d = 64, N a multiple of 256: the causal builds of the slot kernels when the launch fills the chip (fa_api.hip)
-    cblocks = BH * (N // 256)
-    cslot = args.dtype == "bf16" and causal and not args.phased and d == 64 and N % 256 == 0
-    K_FWD = "fwd_slot_kernel" if (bf and ((d == 64) or (d == 128 and N % 64 == 0))) or (cslot and cblocks >= 256) else "fwd_kernel"
-    K_DQ = "bwd_dq_slot_kernel" if (bf and d == 64) or (cslot and cblocks >= 128) else "bwd_dq_kernel"
-    K_DKDV = "bwd_dkdv_slot_kernel" if (bf and d == 64) or (cslot and cblocks >= 128) else "bwd_dkdv_kernel"
-    STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
-              (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)), (K_DQ, lambda: bwd(device_ops.STAGE_DQ)))
-    # The dQ launch preprocesses its own rows and runs BEFORE dK/dV (no preprocess kernel): what fa_mi355x_bwd does in one call, and
-    # the same rule as fa_api.hip's dq_fuses_prep (every plain dQ build folds the preprocess in; the masked d = 64 slot build does not)
-    fuse_prep = (OPTS is None or len(OPTS) < 5 or OPTS[4] == 0) and (args.dtype != "bf16" or N >= 64) and \
-        (K_DQ != "bwd_dq_slot_kernel" or (not causal and N % 128 == 0) or (causal and N % 256 == 0))
-    if fuse_prep:
-        STAGES = ((K_FWD, fwd), (K_DQ, lambda: bwd(device_ops.STAGE_PREP | device_ops.STAGE_DQ)),
-                  (K_DKDV, lambda: bwd(device_ops.STAGE_DKDV)))
-    one_pass = bf and d == 64 and N % 256 == 0 and OPTS is not None and len(OPTS) > 4 and OPTS[4] == 2
-    if one_pass:   # A/B of the opt-in one-pass backward (--opts 0,0,0,0,2): dK/dV and dQ come from ONE kernel
-        STAGES = ((K_FWD, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
-                  ("bwd_fused_kernel", lambda: bwd(device_ops.STAGE_DKDV | device_ops.STAGE_DQ)))
+    # One step = forward + backward; the backward's kernels are launched one by one so that a HIP event can be recorded between
+    # kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).  Which kernels those are, and in which
+    # order, is asked of the library (fa_mi355x_plan runs its dispatch code with the launches skipped): kernel names as rocprofv3
+    # shows them (fa::<name><...>).
+    STAGES, K_FWD, K_DQ, K_DKDV = stage_plan(device_ops, BH, N, d, causal, args.dtype, OPTS, fwd, bwd)
     breakdown = not args.no_kernel_breakdown
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)] \
         if breakdown else None
@@ -331,24 +364,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The clock needs some tens of ms of the SAME load to settle (MI355X_MICROARCH.md, DVFS give-back): whatever --warmup says, the
+    # timed region is preceded by at least SETTLE_MS of back-to-back steps (untimed, reported as settle_ms), then the W warm-up steps.
+    SETTLE_MS = 60.0
+    ts = time.perf_counter()
+    while True:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        settle_ms = (time.perf_counter() - ts) * 1e3
+        if settle_ms >= SETTLE_MS:
+            break
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i] if breakdown else None)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_block(ev_rows):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(ev_rows[i] if ev_rows is not None else None)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed_block(events if breakdown else None)   # the contractual block: EXACTLY --steps steps, barrier + synchronize on both sides
+    # ... and five more blocks of the same length, so that the line carries its own spread (`value` stays the first block's)
+    more_blocks = [timed_block(None) for _ in range(5)]
 
     cf = 0.5 if causal else 1.0
     flops_fw = 4.0 * BH * N * N * d * cf
     flops_bw = 10.0 * BH * N * N * d * cf
     ms_per_step = elapsed / args.steps * 1e3
     value = world * (flops_fw + flops_bw) / (elapsed / args.steps) / 1e12
+    blocks_ms = [round(e / args.steps * 1e3, 4) for e in [elapsed] + more_blocks]
+    med_ms = sorted(blocks_ms)[len(blocks_ms) // 2]
 
     # ---- per-kernel average launch duration from the HIP events recorded in the timed region -------------------
     kernels = {}
@@ -445,7 +498,7 @@ def main():
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = run_extras(torch, device_ops, q, k, v, do, causal)
+        extras = run_extras(torch, device_ops, q, k, v, do, causal, B, H)
 
     if rank == 0:
         line = {
@@ -470,10 +523,15 @@ def main():
             "sustained_mfma_peak": sustained,
             "cpu_baseline": cpu_baseline,
             "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
+            "settle_ms": round(settle_ms, 1),
+            "ms_per_step_blocks": blocks_ms,
+            "ms_per_step_median": med_ms,
+            "value_median": round(world * (flops_fw + flops_bw) / (med_ms * 1e-3) / 1e12, 2),
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "fw_with_gather_ms": None if fw_with_gather_ms is None else round(fw_with_gather_ms, 3),
             "vs_vanilla": extras.get("vs_vanilla"),
             "variants": extras.get("variants"),
+            "ablation": extras.get("ablation"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

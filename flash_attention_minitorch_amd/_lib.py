@@ -109,6 +109,8 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_bwd_ex.restype = _i
     h.fa_mi355x_bwd_status.argtypes = [_vp, _i, _i, _i, _ip]
     h.fa_mi355x_bwd_status.restype = _i
+    h.fa_mi355x_plan.argtypes = [_i] * 7 + [_ip, _i, ctypes.c_char_p, ctypes.c_size_t]
+    h.fa_mi355x_plan.restype = _i
     if DIAG:
         h.fa_mi355x_set_tuning.argtypes = [_i, _i]
         h.fa_mi355x_set_tuning.restype = _i
@@ -128,6 +130,15 @@ def opts_array(opts):
         return None, 0
     arr = (ctypes.c_int * len(opts))(*[int(x) for x in opts])
     return arr, len(opts)
+
+
+def plan(batch, n, d, causal, variant, dtype, stages, opts=None):
+    """Kernel names, in launch order, of the call with these arguments (fa_mi355x_plan: the library's own dispatch code with the
+    launches skipped).  stages = 0: the forward; otherwise the backward stage mask."""
+    arr, cnt = opts_array(opts)
+    buf = ctypes.create_string_buffer(1024)
+    check(core().fa_mi355x_plan(int(batch), int(n), int(d), int(bool(causal)), int(variant), int(dtype), int(stages), arr, cnt, buf, 1024))
+    return [x for x in buf.value.decode().split(";") if x]
 
 
 def check(status: int) -> None:

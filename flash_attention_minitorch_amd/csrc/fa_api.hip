@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <mutex>
+#include <string>
 #include <vector>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +20,8 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+bool plan_mode();   // a fa_mi355x_plan() call is recording on this thread (see FA_LAUNCH)
+
 int set_err(int code, const char* what, hipError_t e = hipSuccess) {
   if (e != hipSuccess)
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -27,10 +30,31 @@ int set_err(int code, const char* what, hipError_t e = hipSuccess) {
   return code;
 }
 
-#define FA_HIP_TRY(expr)                                           \
-  do {                                                             \
-    hipError_t e_ = (expr);                                        \
-    if (e_ != hipSuccess) return set_err(FA_ERR_HIP, #expr, e_);   \
+#define FA_HIP_TRY(expr)                                             \
+  do {                                                               \
+    if (!plan_mode()) {   /* fa_mi355x_plan: no HIP call at all */   \
+      hipError_t e_ = (expr);                                        \
+      if (e_ != hipSuccess) return set_err(FA_ERR_HIP, #expr, e_);   \
+    }                                                                \
+  } while (0)
+
+// Every kernel launch of the dispatch code below goes through FA_LAUNCH.  fa_mi355x_plan() runs the SAME dispatch functions with a
+// recorder installed: the launch is then skipped and the kernel's name appended to the plan, so what bench.py labels and what the
+// library launches cannot drift apart (one source of truth for the kernel selection).
+thread_local std::vector<std::string>* t_plan = nullptr;
+bool plan_mode() { return t_plan != nullptr; }
+void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> "fwd_slot_kernel"
+  const char* b = expr;
+  while (*b == '(' || *b == ' ') ++b;
+  if (strncmp(b, "fa::", 4) == 0) b += 4;
+  const char* e = b;
+  while (*e && *e != '<' && *e != ')' && *e != ' ') ++e;
+  t_plan->emplace_back(b, e);
+}
+#define FA_LAUNCH(kern, grid, block, shmem, st, ...)                        \
+  do {                                                                      \
+    if (t_plan) plan_add(#kern);                                            \
+    else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);     \
   } while (0)
 
 inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
@@ -72,6 +96,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
 constexpr size_t FUSED_CTL_BYTES = fa::FUSED_FLAG0, FUSED_FLAG_BYTES = fa::FUSED_FLAG_BYTES;
 constexpr int FUSED_MAX_CUS = 512;   // sizing bound only (flags: 4 * CUs words; slabs: CUs * 64 KiB)
 inline size_t align256z(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr int WS_VECS = 3;   // row-constant vectors at the head of the backward workspace: -L/tau, -delta, -L*log2(e)
 inline bool fused_shape(int N, int d) { return d == 64 && N >= 256 && N % 256 == 0 && N / 256 <= FUSED_MAX_CUS; }
 inline size_t fused_extra_bytes(int batch, int N, int d) {
   if (!fused_shape(N, d)) return 0;
@@ -121,7 +146,7 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
   fa::Layout lay1 = lay;   // (the follow-up launch of one block per head below is not ranked)
   lay1.rank_chunk = 0;
 #define FA_FWD_LAUNCH(FEAT, CARE, BLOCKS, ONLY)                                                                          \
-  hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, FEAT, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q, \
+  FA_LAUNCH((fa::fwd_kernel<T, D, BN, WPE, FEAT, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q, \
                      (const T*)k, (const T*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau, ONLY)
   if (lay.drop_thr) {   // dropout on P (and the key mask, staged as zeros when absent)
     FA_FWD_LAUNCH(2, BF, nblk, only_qb);
@@ -133,7 +158,7 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
   } else {
     FA_FWD_LAUNCH(0, false, nblk, only_qb);
     if (BF && causal) {   // rows 0..63 see fewer than 64 keys: query block 0 again, split operands
-      hipLaunchKernelGGL((fa::fwd_kernel<T, D, BN, WPE, 0, BF>), dim3(batch), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+      FA_LAUNCH((fa::fwd_kernel<T, D, BN, WPE, 0, BF>), dim3(batch), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
                          out, l, m, N, nqb, batch, lay1, causal, variant, tau, 0);
     }
   }
@@ -158,13 +183,13 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
       if (whole && tun.v[1] == 94 && D == 64) {   // timing ablation: no per-stage barrier (WRONG results)
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 2, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 2, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
       if (whole && tun.v[1] == 93 && D == 64) {   // phase stamps (never timed)
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 1, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 1, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
@@ -173,7 +198,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       if (cslot) {   // (d = 64: four waves per SIMD, two workgroups per CU; d = 128: two waves per SIMD, one workgroup)
         const bool ranked = causal_ranked(tun, batch * nqb, D == 64 ? 2 : 1);
         lay.rank_chunk = rank_chunk(D == 64 ? 2 : 1, nqb);
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>),
+        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>),
                            dim3(ranked ? batch * nqb : batch * ((nqb + 1) / 2)),
                            dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, ranked ? 2 : 1, tau);
         FA_HIP_TRY(hipGetLastError());
@@ -181,19 +206,19 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       }
       if (whole && tun.v[1] != 6 && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
       if (whole) {
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
       if constexpr (D == 64) {   // ragged N / forced causal: the variant with masked periods (d = 128 takes the phased kernel)
-        hipLaunchKernelGGL((fa::fwd_slot_kernel<T, D, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH((fa::fwd_slot_kernel<T, D, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         // under the causal mask rows 0..63 see fewer than 64 keys: the slot kernel has no split-operand path, so the phased
@@ -220,7 +245,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   const int nkb = (N + NW * KPW - 1) / (NW * KPW);
   const int nkb4 = (N + 127) / 128;
 #define FA_CARE_LAUNCH(HD, GRID, THIN)                                                                                        \
-  hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 4, 64, 1, HD, 1, BF>), dim3(GRID), dim3(256), 0, st, (const T*)q, (const T*)k, \
+  FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, 32, 4, 64, 1, HD, 1, BF>), dim3(GRID), dim3(256), 0, st, (const T*)q, (const T*)k, \
                      (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb4, batch, lay, causal, tau, THIN)
   if (lay.drop_thr) {   // dropout: the plain per-sub-slice path regenerates the mask from (bh, query, key)
     // (these whole-launch builds take one key block per workgroup: under the causal mask longest first across a chunk of heads)
@@ -229,7 +254,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
       FA_CARE_LAUNCH(true, batch * nkb4, 0);
     } else {
       if (causal && rank_causal) lay.rank_chunk = rank_chunk(2, nkb);
-      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
+      FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, 1, true>), dim3(batch * nkb), dim3(NW * 64), 0, st,
                          (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
                          causal, tau, 0);
     }
@@ -246,7 +271,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   }
   if constexpr (BF && MODE == 3) {
     if (causal && care_main) {   // d = 64 default: the split-operand path inside the main (paired) kernel: 2 % faster than main + corner launch
-      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE, false, 1, true, true>), dim3(batch * ((nkb + 1) / 2)),
+      FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE, false, 1, true, true>), dim3(batch * ((nkb + 1) / 2)),
                          dim3(NW * 64), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch,
                          lay, causal, tau, 0);
       FA_HIP_TRY(hipGetLastError());
@@ -260,7 +285,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   // (MODE 3 always runs its paired build: hipcc's allocation of the unpaired MODE 3 instance spills, the paired one does not)
   if ((causal || MODE == 3) && CAN_PAIR) {
     if constexpr (CAN_PAIR)
-      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE, false, 1, false, true>), dim3(batch * ((nkb + 1) / 2)),
+      FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE, false, 1, false, true>), dim3(batch * ((nkb + 1) / 2)),
                          dim3(NW * 64), 0, st, (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch,
                          lay, causal, tau, thin);
   } else {
@@ -268,7 +293,7 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
     // 2.05 vs 2.21 ms at configs[3]'s shape, 0.157 vs 0.207 at B = 8, N = 2048 (option 7 = 1: head by head)
     if (causal && rank_causal) lay.rank_chunk = rank_chunk(NW == 8 ? 1 : 2, nkb);
     if constexpr (MODE != 3 || !CAN_PAIR)
-      hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
+      FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, KPW, NW, QS, MODE>), dim3(batch * nkb), dim3(NW * 64), 0, st, (const T*)q,
                          (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, causal, tau, thin);
   }
   if constexpr (BF) {
@@ -292,7 +317,7 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
   fa::Layout lay1 = lay;   // (the follow-up launch of one block per head below is not ranked)
   lay1.rank_chunk = 0;
 #define FA_DQ_LAUNCH(FEAT, CARE, BLOCKS, ONLY)                                                                              \
-  hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, FEAT, 4, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q,   \
+  FA_LAUNCH((fa::bwd_dq_kernel<T, D, BN, FEAT, 4, CARE>), dim3(batch * (BLOCKS)), dim3(256), 0, st, (const T*)q,   \
                      (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, ONLY, fa::DqPrep{})
   if (lay.drop_thr) {
     FA_DQ_LAUNCH(2, BF, nblk, only_qb);
@@ -302,12 +327,12 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
     FA_DQ_LAUNCH(0, BF, nblk, only_qb);
   } else {
     if (prep)
-      hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 0, 4, false, true>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
+      FA_LAUNCH((fa::bwd_dq_kernel<T, D, BN, 0, 4, false, true>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
                          (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb, *prep);
     else
       FA_DQ_LAUNCH(0, false, nblk, only_qb);
     if (BF && causal)   // rows 0..63 again with split operands
-      hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, BN, 0, 4, BF>), dim3(batch), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+      FA_LAUNCH((fa::bwd_dq_kernel<T, D, BN, 0, 4, BF>), dim3(batch), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
                          (const T*)dout, nlc, delta, dq, N, nqb, batch, lay1, causal, tau, 0, fa::DqPrep{});
   }
 #undef FA_DQ_LAUNCH
@@ -327,20 +352,20 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
     // longest first across all heads (paired: blocks p and nqb-1-p in one workgroup)
     const dim3 grid(paired ? batch * ((nqb + 1) / 2) : batch * nqb);
     if (prep)
-      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
                          (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, *prep);
     else
-      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
                          (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, fa::DqPrep{});
   } else if (DIAG == 0 && !causal && N % 128 == 0) {   // no sub-tile needs a mask: the build without masked period variants
     if (prep)
-      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                          (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, *prep);
     else
-      hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                          (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, fa::DqPrep{});
   } else {
-    hipLaunchKernelGGL((fa::bwd_dq_slot_kernel<T, D, DIAG>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+    FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, DIAG>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, fa::DqPrep{});
   }
   FA_HIP_TRY(hipGetLastError());
@@ -379,10 +404,10 @@ int dq_stage(const void* q, const void* k, const void* v, const void* dout, cons
     else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
       const int nqb = (N + 255) / 256;
       if (prep)
-        hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, 32, 0, 8, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH((fa::bwd_dq_kernel<T, D, 32, 0, 8, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, *prep);
       else
-        hipLaunchKernelGGL((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+        FA_LAUNCH((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                            (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, fa::DqPrep{});
       FA_HIP_TRY(hipGetLastError());
       rc = FA_OK;
@@ -429,17 +454,18 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
                float* dv, const float* l, const float* m, float* ws, int batch, int N, fa::Layout lay, int causal,
                int variant, float tau, int stages, hipStream_t st, const Tun& tun) {
   const long rows = (long)batch * N;
-  float* nlc = ws;
-  float* delta = ws + rows;
+  float* nlc = ws;              // -L / tau        (raw score units)
+  float* delta = ws + rows;     // -rowsum(dO * O)
+  float* nl2 = ws + 2 * rows;   // -L * log2(e)    (the slot dK/dV kernel: its K fragments carry tau*log2(e))
   constexpr int RPB = 256 / (D / 8);
   const bool fuse_prep = dq_fuses_prep<T, D>(batch, N, lay, causal, stages, tun);
   if ((stages & FA_BWD_STAGE_PREP) && !fuse_prep) {
-    hipLaunchKernelGGL((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
-                       (const T*)dout, l, m, nlc, delta, rows, N, lay, variant, 1.0f / tau);
+    FA_LAUNCH((fa::bwd_prep_kernel<T, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, out,
+                       (const T*)dout, l, m, nlc, delta, nl2, rows, N, lay, variant, 1.0f / tau);
     FA_HIP_TRY(hipGetLastError());
   }
   if (fuse_prep) {   // dQ first: it preprocesses its own rows and leaves -L/tau, -delta in the workspace for the dK/dV kernel
-    const fa::DqPrep pa{out, l, m, nlc, delta, variant, 1.0f / tau};
+    const fa::DqPrep pa{out, l, m, nlc, delta, nl2, variant, 1.0f / tau};
     const int rc = dq_stage<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, &pa);
     if (rc) return rc;
   }
@@ -456,11 +482,11 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       const int avail = xcdmap ? 8 * (32 / nkb) : cus / nkb;
       const int ngroups = std::min(avail, batch);
       const int grid = xcdmap ? 256 : ngroups * nkb;
-      char* fz = (char*)ws + align256z((size_t)2 * rows * sizeof(float));
+      char* fz = (char*)ws + align256z((size_t)WS_VECS * rows * sizeof(float));
       unsigned* hand = (unsigned*)fz;
       FA_HIP_TRY(hipMemsetAsync(fz, 0, FUSED_CTL_BYTES + FUSED_FLAG_BYTES + fa::FUSED_PAGES / 2, st));   // error word, flags, zero page: every call
 #define FA_FUSED_LAUNCH(ABL)                                                                                              \
-  hipLaunchKernelGGL((fa::bwd_fused_kernel<T, 64, ABL>), dim3(grid), dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, \
+  FA_LAUNCH((fa::bwd_fused_kernel<T, 64, ABL>), dim3(grid), dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, \
                      (const T*)dout, nlc, delta, dq, dk, dv, hand, N, nkb, batch, ngroups, xcdmap, lay, tau)
 #ifdef FA_DIAG
       switch (tun.v[5]) {   // timing ablations (wrong results) and phase stamps: see bwd_fused_kernel
@@ -508,8 +534,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (D == 64 && !causal && tun.v[0] == 193 && !lay.drop_thr) {   // continuous slot pipeline with phase stamps
         const int nkb = (N + 255) / 256;
-        hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
-                           (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
       }
@@ -528,11 +554,11 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         }
         if (tiles > 1) {
           lay.tiles = tiles;
-          hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
-                             (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+          FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
+                             (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         } else {
-          hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
-                             (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+          FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                             (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         }
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
@@ -542,8 +568,8 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // diagonal block, the block per wave, workgroups longest first); tuning key 0 = 3: the phased kernel below
         const int nkb = N / 256;
         lay.rank_chunk = rank_chunk(1, nkb);
-        hipLaunchKernelGGL((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
-                           (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay, tau);
+        FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
       } else   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
@@ -565,7 +591,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (tun.v[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves
         const int nkb = (N + 255) / 256;
-        hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 8, 32, 0, false, 2>), dim3(batch * nkb), dim3(512), 0, st,
+        FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, 32, 8, 32, 0, false, 2>), dim3(batch * nkb), dim3(512), 0, st,
                            (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
                            causal, tau);
         FA_HIP_TRY(hipGetLastError());
@@ -575,7 +601,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // causal: longest block first across a chunk of heads instead of head by head: 0.57 vs 0.80 ms at the reference's timing-harness
         // shape (B = 8, H = 8, N = 2048, fp32), bitwise the same (option 7 = 1: head by head)
         if (causal && tun.v[7] != 1) lay.rank_chunk = rank_chunk(2, nkb);
-        hipLaunchKernelGGL((fa::bwd_dkdv_kernel<T, D, 32, 4, 32, 0, false, 2>), dim3(batch * nkb), dim3(256), 0, st,
+        FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, 32, 4, 32, 0, false, 2>), dim3(batch * nkb), dim3(256), 0, st,
                            (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
                            causal, tau);
         FA_HIP_TRY(hipGetLastError());
@@ -817,6 +843,31 @@ int fa_mi355x_measure_mfma_peak(double min_ms, double* tflops, double* clock_ghz
   return FA_OK;
 }
 
+int fa_mi355x_plan(int batch, int N, int d, int causal, int variant, int dtype, int stages, const int* opts, int nopts, char* out,
+                   size_t n) {
+  g_err[0] = 0;
+  Tun tun;
+  if (int rc = parse_opts(opts, nopts, tun)) return rc;
+  if (stages < 0 || stages > FA_BWD_STAGE_ALL) return set_err(FA_ERR_BAD_ARG, "bad stages mask");
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (!out || n == 0) return set_err(FA_ERR_BAD_ARG, "null output buffer");
+  std::vector<std::string> names;
+  t_plan = &names;
+  // the dispatch functions only pass their pointers on to the (skipped) launches: any non-null values do
+  float* one = reinterpret_cast<float*>(16);
+  const int rc = stages == 0 ? fwd_dispatch(one, one, one, one, one, one, batch, N, d, d, bhnd(N, d), causal ? 1 : 0, variant, dtype, nullptr, tun)
+                             : bwd_dispatch(one, one, one, one, one, one, one, one, one, one, one, batch, N, d, d, bhnd(N, d), causal ? 1 : 0,
+                                            variant, dtype, stages, nullptr, tun);
+  t_plan = nullptr;
+  if (rc) return rc;
+  std::string joined;
+  for (size_t i = 0; i < names.size(); ++i) joined += (i ? ";" : "") + names[i];
+  if (joined.size() + 1 > n) return set_err(FA_ERR_BAD_ARG, "plan buffer too small");
+  memcpy(out, joined.c_str(), joined.size() + 1);
+  return FA_OK;
+}
+
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                   int d, int causal, int variant, int dtype, void* stream) {
   g_err[0] = 0;
@@ -975,7 +1026,7 @@ int fa_mi355x_bwd_dropout(const void* q, const void* k, const void* v, const flo
 
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d) {
   if (batch <= 0 || N <= 0) return 0;
-  const size_t rowc = (size_t)2 * batch * N * sizeof(float);
+  const size_t rowc = (size_t)WS_VECS * batch * N * sizeof(float);
   const size_t extra = fused_extra_bytes(batch, N, d);
   return extra ? align256z(rowc) + extra : rowc;
 }
@@ -986,7 +1037,7 @@ int fa_mi355x_bwd_status(const void* workspace, int batch, int N, int d, int* st
   *status = 0;
   if (!fused_extra_bytes(batch, N, d)) return FA_OK;
   unsigned word = 0;
-  FA_HIP_TRY(hipMemcpy(&word, (const char*)workspace + align256z((size_t)2 * batch * N * sizeof(float)), sizeof(word),
+  FA_HIP_TRY(hipMemcpy(&word, (const char*)workspace + align256z((size_t)WS_VECS * batch * N * sizeof(float)), sizeof(word),
                        hipMemcpyDeviceToHost));
   *status = (int)word;
   if (word) return set_err(FA_ERR_HIP, "one-pass backward: a hand-off wait timed out (a chain member was not running)");
@@ -1078,7 +1129,7 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
   const size_t rows = (size_t)batch * N;
   const size_t tb = align256(rows * dp * sizeof(float)), rb = align256(rows * sizeof(float));
   std::lock_guard<std::mutex> lock(g_pool_mu);
-  FA_HOST_TRY(pool_reserve(8 * tb + 4 * rb));
+  FA_HOST_TRY(pool_reserve(8 * tb + (2 + WS_VECS) * rb + 256));
   g_pipe.init();
   char* p = (char*)g_pool;
   float* bq = (float*)p;
@@ -1091,7 +1142,7 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
   float* bdv = (float*)(p + 7 * tb);
   float* bl = (float*)(p + 8 * tb);
   float* bm = (float*)(p + 8 * tb + rb);
-  float* ws = (float*)(p + 8 * tb + 2 * rb);   // 2 * rows floats: -L/tau and -delta of every chunk at its own rows
+  float* ws = (float*)(p + 8 * tb + 2 * rb);   // WS_VECS * rows floats: the row constants of every chunk at its own rows
   const size_t tbytes = rows * d * sizeof(float), rbytes = rows * sizeof(float);
   HostTimer tm("bw");
   Pinned pq(q, tbytes), pk(k, tbytes), pv(v, tbytes), po(out, tbytes), pdo(out_grad, tbytes), pl(l, rbytes), pm(m, rbytes),
@@ -1112,9 +1163,9 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
     FA_HOST_TRY(hipMemcpyAsync(bm + r0, m + r0, nr * sizeof(float), hipMemcpyHostToDevice, g_pipe.up));
     FA_HOST_TRY(hipEventRecord(g_pipe.event(2 * c), g_pipe.up));
     FA_HOST_TRY(hipStreamWaitEvent(st, g_pipe.event(2 * c), 0));
-    // the chunk's two row-constant vectors sit at ws + 2 * r0 (the kernels take ws and ws + rows of THEIR launch)
+    // the chunk's row-constant vectors sit at ws + WS_VECS * r0 (the kernels take ws, ws + rows, ws + 2 * rows of THEIR launch)
     if (bwd_dispatch(bq + r0 * dp, bk + r0 * dp, bv + r0 * dp, bo + r0 * dp, bdo + r0 * dp, bdq + r0 * dp, bdk + r0 * dp,
-                     bdv + r0 * dp, bl + r0, bm + r0, ws + 2 * r0, nb, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0, variant,
+                     bdv + r0 * dp, bl + r0, bm + r0, ws + WS_VECS * r0, nb, N, d, dp, bhnd(N, dp), causal_mask ? 1 : 0, variant,
                      FA_DTYPE_F32, FA_BWD_STAGE_ALL, st))
       die(g_err, hipSuccess);
     FA_HOST_TRY(hipEventRecord(g_pipe.event(2 * c + 1), st));

@@ -122,6 +122,14 @@ template <> struct Atom<bf16_t> {
     return __builtin_bit_cast(frag, u);
   }
   static constexpr bool SPLITS = true;
+  // the fragment times a scalar, re-rounded to bf16: the slot kernels fold tau*log2(e) into their lane-stationary operand once
+  // per block (Q in the forward / dQ kernels, K in the dK/dV kernel), so that P = exp2(S') needs no multiply per score
+  static FA_DEV frag scale(const frag& a, float c) {
+    frag o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)a[j] * c);
+    return o;
+  }
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
@@ -179,6 +187,12 @@ template <> struct Atom<float> {
   }
   static FA_DEV frag pack_lo(const f32x16&, int, const frag&) { return zero(); }   // pack() is exact
   static constexpr bool SPLITS = false;
+  static FA_DEV frag scale(const frag& a, float c) {
+    frag o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = a[j] * c;
+    return o;
+  }
   static FA_DEV void mma(f32x16& acc, const frag& a, const frag& b) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);

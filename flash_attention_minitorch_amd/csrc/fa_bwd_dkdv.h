@@ -9,13 +9,14 @@ namespace fa {
 // Backward preprocess: ndelta = -rowsum(dO * O), nlc = -L / tau (raw score units) with L = m + log(l) (FA-1 side
 // outputs) or L = l (FA-2), so that P = exp2(tau*log2e * ((q.k) + nlc)) and dS = P * (dO.V^T + ndelta): both row
 // constants enter the main kernels as MFMA accumulator inputs (S' = Q.K^T + nlc, dP' = dO.V^T + ndelta).  The reference recomputes D_i per (i, j) tile
-// (src/flash_attn_bw.cu:194-197); once per row gives the same value.
+// (src/flash_attn_bw.cu:194-197); once per row gives the same value.  nl2 = -L * log2(e) is the same constant in log2 units, for
+// the kernels whose key / query operand carries tau*log2(e) already (bwd_dkdv_slot_kernel: P = exp2(Q.(cK)^T + nl2)).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int D>
 __global__ void __launch_bounds__(256)
 bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ l,
-                const float* __restrict__ m, float* __restrict__ nlc, float* __restrict__ ndelta, long rows, int N,
-                Layout lay, int aux_mode, float inv_tau) {
+                const float* __restrict__ m, float* __restrict__ nlc, float* __restrict__ ndelta, float* __restrict__ nl2,
+                long rows, int N, Layout lay, int aux_mode, float inv_tau) {
   constexpr int LPR = D / 8;  // lanes per row, 8 elements each
   constexpr int RPB = 256 / LPR;
   const int tid = threadIdx.x;
@@ -37,6 +38,7 @@ bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const f
     ndelta[row] = -sum;
     const float L = (aux_mode == AUX_FA1) ? (m[row] + __logf(l[row])) : l[row];
     nlc[row] = (L == -INFINITY) ? -INFINITY : -L * inv_tau;   // fully masked row: P = exp2(c * (S - inf)) = 0
+    nl2[row] = (L == -INFINITY) ? -INFINITY : -L * LOG2E;
   }
 }
 
@@ -613,10 +615,14 @@ bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 // those stores.  In-kernel stamps (tools/phase_cycles.py 393) put the un-overlapped head and tail of a
 // one-block workgroup at 8 % of its life (1.6 k cycles of set-up, 5.5 k waiting for fragments and stage 0, 7 k until the stores
 // have drained, of 200 k): with one workgroup per CU nothing else runs there meanwhile.
+// Scaling: tau*log2(e) is folded into the K fragments once per key block (re-rounded to bf16) and the row constant arrives in log2
+// units (nl2 = -L*log2(e), the workspace's third vector), so S' = Q (cK)^T + nl2 leaves the MFMA chain as the exp2 argument: ONE
+// instruction per score.  The sub-slices of queries 0..63 in the causal build's diagonal block (fewer than 64 admissible keys) take
+// the unscaled K and the fp32 fma instead.  The launcher never sends a key mask here.
 template <typename T, int D, int DIAG = 0, bool CDIAG = false, bool TILED = false>
 __global__ void __launch_bounds__(512)
 bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
-                     const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
+                     const float* __restrict__ nl2, const float* __restrict__ ndelta, float* __restrict__ dk,
                      float* __restrict__ dv, int N, int nkb, int BH, Layout lay, float tau) {
   static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
   using A = Atom<T>;
@@ -645,7 +651,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   rsrc_t krs = make_rsrc(k + base, mat_bytes);
   rsrc_t vrs = make_rsrc(v + base, mat_bytes);
   raw_rsrc_t qraw = make_raw_rsrc(q + base, mat_bytes), doraw = make_raw_rsrc(dout + base, mat_bytes);
-  raw_rsrc_t nlraw = make_raw_rsrc(nlc + (size_t)bh * N, (uint32_t)N * 4u);
+  raw_rsrc_t nlraw = make_raw_rsrc(nl2 + (size_t)bh * N, (uint32_t)N * 4u);
   raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
   const float c = tau * LOG2E;
   const int kw0 = kb * BK + w * KPW;
@@ -661,8 +667,11 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     }
   };
   load_kv(kw0);
+  auto scale_k = [&]() {   // (called where the fragments are first needed: scaling them forces the wait for their loads)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) kf[kc] = A::scale(kf[kc], c);
+  };
   const int key = kw0 + r;
-  const float km = (lay.kmask != nullptr && key < N) ? lay.kmask[(size_t)(bh / lay.mask_heads) * N + key] * LOG2E : 0.f;
   f32x16 acc_dk[2], acc_dv[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
@@ -708,6 +717,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   // LDS-DMA of the next stage that the loop has just issued.
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(kf[kc]), "v"(vf[kc]));
+  scale_k();
   __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
@@ -733,7 +743,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
       for (int j = 0; j < 4; ++j) x[4 * g + j] = a[j];
     }
   };
-  auto me = [&](f32x16& x, int i) { x[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], c, km)); };
+  auto me = [&](f32x16& x, int i) { x[i] = __builtin_amdgcn_exp2f(x[i]); };
   // One period.  SN: sub-slice whose S', dP' are produced, rows at (nr0, nr1) [its dO rows 1..3 are requested here]; SC:
   // sub-slice in the softmax / dV, dK stream, transposed reads at (ct0, ct1); SP: the sub-slice after SN, whose Q rows, row
   // constants and first dO row are requested in slots 12-15 at (pr0, pr1, ph16).
@@ -830,6 +840,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   if (TILED && t) {   // the fragments of this head were requested before the previous head's stores (see below)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(kf[kc]), "v"(vf[kc]));
+    scale_k();
   }
   const int b0 = slot_of(st0);   // addresses of the current stage
   int cr0 = ra.b[0] + b0, cr1 = ra.b[1] + b0, ct0 = ta.b[0] + b0, ct1 = ta.b[1] + b0, ch16 = 16 * h + b0;
@@ -852,7 +863,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
       const size_t nbase = head_base(lay, bh + 1);
       qraw = make_raw_rsrc(q + nbase, mat_bytes);
       doraw = make_raw_rsrc(dout + nbase, mat_bytes);
-      nlraw = make_raw_rsrc(nlc + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
+      nlraw = make_raw_rsrc(nl2 + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
       ndraw = make_raw_rsrc(ndelta + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
       stage_dma(0, nb);
     }
@@ -909,6 +920,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     if (st0 >= nst) {   // (the last key block has no stage below its diagonal block)
       stage_dma(2 * kb, slot_of(nst));
       stage_dma(2 * kb + 1, slot_of(nst + 1));
+      scale_k();        // (the sweep, which scales the K fragments at its top, did not run)
     }
     dma_wait_all();
     __syncthreads();
@@ -929,20 +941,41 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
         }
       }
       f32x16 s, dp;
+      const bool exactk = A::SPLITS && qi0 < 64;   // wave-uniform: queries with fewer than 64 admissible keys (key block 0 only)
+      if (exactk) {   // the unscaled K and the fp32 fma (the rounding of cK is the same for every query and these rows average nothing out)
+        frag ku[KC];
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const frag aq = A::template row_frag<D>(tq, ra, 32 * sub, kc);
-        const frag ado = A::template row_frag<D>(tdo, ra, 32 * sub, kc);
-        if (kc == 0) {   // row constants ride in as accumulator inputs: S' = S - L/tau, dP' = dP - delta
-          A::mma_c(s, aq, kf[kc], nl16);
-          A::mma_c(dp, ado, vf[kc], nd16);
-        } else {
-          A::mma(s, aq, kf[kc]);
-          A::mma(dp, ado, vf[kc]);
+        for (int kc = 0; kc < KC; ++kc) ku[kc] = load_frag_buf<T>(krs, ((kw0 + r) * ld + 16 * kc + 8 * h) * (int)sizeof(T));
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const frag aq = A::template row_frag<D>(tq, ra, 32 * sub, kc);
+          const frag ado = A::template row_frag<D>(tdo, ra, 32 * sub, kc);
+          if (kc == 0) {
+            A::mma_c(s, aq, ku[kc], zero16());
+            A::mma_c(dp, ado, vf[kc], nd16);
+          } else {
+            A::mma(s, aq, ku[kc]);
+            A::mma(dp, ado, vf[kc]);
+          }
         }
-      }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, km));
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nl16[i]));
+      } else {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const frag aq = A::template row_frag<D>(tq, ra, 32 * sub, kc);
+          const frag ado = A::template row_frag<D>(tdo, ra, 32 * sub, kc);
+          if (kc == 0) {   // row constants ride in as accumulator inputs: S' = c S - L log2e, dP' = dP - delta
+            A::mma_c(s, aq, kf[kc], nl16);
+            A::mma_c(dp, ado, vf[kc], nd16);
+          } else {
+            A::mma(s, aq, kf[kc]);
+            A::mma(dp, ado, vf[kc]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+      }
       if (j == w) {   // this wave's own 32 queries: key kw0 + r against query qi0 + row
 #pragma unroll
         for (int i = 0; i < 16; ++i)

@@ -16,6 +16,7 @@ struct DqPrep {
   const float* m;      // FA-1: row maximum (else unused)
   float* nlc;          // workspace, written: -L / tau
   float* ndelta;       // workspace, written: -rowsum(dO * O)
+  float* nl2;          // workspace, written: -L * log2(e)  (what the dK/dV slot kernel takes as its accumulator input)
   int aux_mode;
   float inv_tau;
 };
@@ -41,6 +42,7 @@ FA_DEV void dq_prep_rows(const DqPrep& pa, const typename Atom<T>::frag (&dof)[K
   if (qvalid && h == 0) {
     pa.nlc[(size_t)bh * N + qrow] = nl;
     pa.ndelta[(size_t)bh * N + qrow] = -sum;
+    pa.nl2[(size_t)bh * N + qrow] = nl * c;
   }
   nlq = qvalid ? nl * c : 0.f;
   ndq = qvalid ? -sum : 0.f;
@@ -330,12 +332,24 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
     ndq = qvalid ? ndelta[(size_t)bh * N + qrow] : 0.f;
   }
+  // PRE (the builds without masked periods): tau*log2(e) is folded into the Q fragments once per block (re-rounded to bf16) and
+  // -L*log2(e) enters S^T as the accumulator input of its MFMA chain, so P = exp2(S') is ONE instruction per score.  Rows with fewer
+  // than 64 admissible keys (causal build, query block 0: no sweep, only the diagonal block) keep the unscaled Q and the fp32 fma.
+  constexpr bool PRE = !MASKS;
+  const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform
+  if (PRE && !exactq) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qf[kc] = A::scale(qf[kc], c);
+  }
   // -delta enters dP^T as the accumulator input of its MFMA chain (sixteen registers holding one value).  The build with masked
   // periods has no registers for that (it spilled three around the loop): there the VALU adds it, dS = P * (dP + (-delta)).
   constexpr bool NDACC = !MASKS;
-  f32x16 nd16;
+  f32x16 nd16, nl16;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) nd16[i] = NDACC ? ndq : 0.f;
+  for (int i = 0; i < 16; ++i) {
+    nd16[i] = NDACC ? ndq : 0.f;
+    nl16[i] = PRE ? nlq : 0.f;
+  }
   f32x16 acc[2];
   acc[0] = zero16();
   acc[1] = zero16();
@@ -407,7 +421,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     float cm = c;
     if constexpr (MASK) asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the masked and unmasked variants' common fma
     auto fe = [&](int i) {
-      float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nlq));
+      float pv = PRE ? __builtin_amdgcn_exp2f(cs[i]) : __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nlq));
       if constexpr (MASK) pv = (acc_row(i, h) > klim) ? 0.f : pv;
       cs[i] = pv;
     };
@@ -421,7 +435,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {   // slots 0-3: S^T of the next sub-tile
       if constexpr (HN) {
-        if (kq == 0) A::mma_c(ns, rk[0], qf[0], zero16());
+        if (kq == 0) A::mma_c(ns, rk[0], qf[0], PRE ? nl16 : zero16());
         else A::mma(ns, rk[kq], qf[kq]);
         SB();   // the MFMA opens its slot; the fillers follow in its shadow
         if constexpr (LEAD == 4) rv[kq] = vrow(kq);
@@ -559,7 +573,8 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     }
     dma_wait_all();
     __syncthreads();
-    const bool careful = A::SPLITS && q0 < 64;   // wave-uniform
+    const bool careful = exactq;   // wave-uniform
+    const float cmd = exactq ? c : 1.0f;   // (the other waves' scores leave the MFMA chain in log2 units)
     for (int j = 0; j <= w; ++j) {
       const int sb = ((nstage + (j >> 2)) % 3) * TB;
       lds_char* tk = smem + sb;
@@ -574,7 +589,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
         A::mma(dp, A::template row_frag<D>(tv, ra, row32, kc), dof[kc]);
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nlq));
+      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], cmd, nlq));
       if (j == w) {   // this wave's own 32 keys: key kmax + 32 * w + row against query q0 + r
 #pragma unroll
         for (int i = 0; i < 16; ++i)

@@ -272,6 +272,87 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cold path of the reference-free slot builds (fwd_slot_kernel, MASKS = false): one wave redoes its 32 query rows the classic way
+// (running maximum, O and l rescaled, exact fp32 scaling of the UNSCALED Q, P split into two bf16 fragments), everything straight from
+// global memory: no LDS, no barrier, so the other waves of the workgroup are not involved.  Taken when a row's sum of exp2(S') left
+// [2^-96, 2^96] (or is NaN): |tau q.k| beyond about 58 somewhere in the row.  Slow (scalar gathers of V^T), correct for any input the
+// phased kernel is correct for.  On return acc_o / l_run are relative to m_ref, the row maximum in log2 units (tau*log2e * q.k).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+FA_DEV void fwd_redo_rows(rsrc_t qrs, rsrc_t krs, rsrc_t vrs, int qrow, int q0, int ld, int N, bool causal, float c, int r, int h,
+                          f32x16 (&acc_o)[D / 32], float& m_ref, float& l_run) {
+  using A = Atom<bf16_t>;
+  typedef A::frag frag;
+  constexpr int KC = D / 16, DT = D / 32;
+  // every address below is formed from opaque copies of the lane's coordinates: hoisted to kernel entry (they are loop invariants
+  // of the caller) they would be spilled around its pipeline
+  asm volatile("" : "+v"(r), "+v"(h), "+v"(qrow));
+  frag qf[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<bf16_t>(qrs, (qrow * ld + 16 * kc + 8 * h) * 2);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc_o[dt] = zero16();
+  m_ref = 0.f;
+  l_run = 0.f;
+  const int kend = causal ? min(N, q0 + 32) : N;   // wave-uniform
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    f32x16 s;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const frag kk = load_frag_buf<bf16_t>(krs, ((k0 + r) * ld + 16 * kc + 8 * h) * 2);   // rows >= N read as zero
+      if (kc == 0) A::mma_c(s, kk, qf[0], zero16());
+      else A::mma(s, kk, qf[kc]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = k0 + acc_row(i, h);
+      if (key >= N || (causal && key > qrow)) s[i] = -INFINITY;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+    mx = xhalf_max(mx) * c;   // log2 units; key 0 is admissible for every row, so the first sub-tile's maximum is finite
+    float alpha = 1.0f;
+    if (k0 == 0) {
+      m_ref = mx;
+    } else {
+      const float delta = fmaxf(mx - m_ref, 0.f);
+      if (__any(delta > 0.f)) {
+        alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_o[dt][i] *= alpha;
+        m_ref += delta;
+      }
+    }
+    const float nm = -m_ref;
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nm));
+      rs += s[i];
+    }
+    l_run = l_run * alpha + rs;
+    const frag pf0 = A::pack(s, 0), pf1 = A::pack(s, 1);
+    const frag pl0 = A::pack_lo(s, 0, pf0), pl1 = A::pack_lo(s, 1, pf1);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+        u16x8 raw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)   // element j: V[k0 + 16*s2 + 8*(j>>2) + 4*h + (j&3)][32*dt + r]  (Atom::tr_frag's map)
+          raw[j] = __builtin_amdgcn_raw_buffer_load_b16(vrs, ((k0 + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * ld + 32 * dt + r) * 2, 0, 0);
+        const frag vt = __builtin_bit_cast(frag, raw);
+        A::mma(acc_o[dt], vt, s2 ? pf1 : pf0);
+        A::mma(acc_o[dt], vt, s2 ? pl1 : pl0);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward, slot-interleaved (bf16, d = 64 or 128, FA-2 side output): a workgroup = 8 waves = 256 query rows (two waves
 // per SIMD), query on the lane as above.  K / V arrive by LDS-DMA in 16 KiB stages (128 keys at d = 64, 64 at d = 128;
 // K and V rings of R slots, V above K) and are consumed as 32-key sub-tiles by a three-deep software pipeline of MFMA
@@ -315,6 +396,13 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   constexpr int SUBB = (D / 32) * 512 * 4;            // bytes of one 32-key sub-tile inside a stage image
   static_assert((TB == 16384 || TB == 8192) && 2 * DT == KC && (NSUBT == 2 || NSUBT == 4), "stage geometry");
   static_assert(!CDIAG || (!MASKS && NSUBT == 2 && R * ST == 256), "causal build: the ring holds one 256-key diagonal block");
+  // PRE (every build without masked periods): tau*log2(e) is folded into the Q fragments once per block (re-rounded to bf16), so
+  // S' = K (cQ)^T leaves the MFMA chain in log2 units, and the sweep runs WITHOUT a reference: P = exp2(S'), one v_exp + one v_add
+  // per score instead of fma + exp + add, no row maximum, no redo branch.  fp32 / bf16 carry exp2(S') at full relative precision
+  // for |S'| up to ~100 (|tau q.k| up to ~58 natural units); a wave whose row sum left [2^-96, 2^96] redoes its rows in the cold
+  // path above (fwd_redo_rows).  Rows with fewer than 64 admissible keys (causal build, query block 0) keep the unscaled Q and the
+  // exact fp32 scaling: the rounding of cQ is common to all keys of a row and is only averaged out over many keys.
+  constexpr bool PRE = !MASKS;
   __shared__ __attribute__((aligned(16))) char smem_raw[2 * R * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
@@ -343,10 +431,16 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   frag qf[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
+  const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform: rows with fewer than 64 admissible keys (query block 0 only)
+  if (PRE && !exactq) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qf[kc] = A::scale(qf[kc], c);
+  }
+  const float cm = (PRE && !exactq) ? 1.0f : c;   // what a score of this wave's MFMA chain is multiplied by to reach log2 units
   f32x16 acc_o[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc_o[dt] = zero16();
-  float m_ref = 0.f, nmc = 0.f, l_run = 0.f;
+  float m_ref = 0.f, nmc = 0.f, l_run = 0.f;   // m_ref: raw score units; PRE builds: log2 units (0 throughout the sweep)
 
   const LaneAddr ra = A::template row_addr<D>(lane);
   const LaneAddr ta = A::template tr_addr<D>(lane);
@@ -435,7 +529,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       if constexpr (HC) mask_scores(cs, kcur);
     }
     auto fe = [&](int i) {
-      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nmc));
+      const float pv = PRE ? __builtin_amdgcn_exp2f(cs[i]) : __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nmc));
       cs[i] = pv;
       rs += pv;
     };
@@ -483,7 +577,8 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       }
       SB();
     }
-    if constexpr (HC) {
+    if constexpr (HC && PRE) l_run += rs;   // no reference to move: the range check sits at the end of the block
+    if constexpr (HC && !PRE) {
       float alpha = 1.0f;
       if (__any(!(rs < MAX_DEFER_SUM))) {   // rare: some row outgrew its reference -> redo this sub-tile the classic way
 #pragma unroll
@@ -527,7 +622,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   pB0 = pB1 = pA0 = pA1 = u32x4{0u, 0u, 0u, 0u};
   SB();
   period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, cr0, cr1, cr0, cr1, 0, sA, sB, pB0, pB1, pA0, pA1);
-  {
+  if constexpr (!PRE) {
     const bool m0 = MASKS && ((31 >= N) || (causal && 31 > q0));
     if (m0) mask_scores(sA, 0);
     m_ref = tile_max(sA);      // key 0 is never masked, so the maximum is finite
@@ -618,7 +713,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     __syncthreads();   // slots 0, 1 published; every wave is past its last read of slots 2, 3
     stage_dma(kmax + 2 * ST, 2 * TB);
     stage_dma(kmax + 3 * ST, 3 * TB);
-    const bool careful = A::SPLITS && q0 < 64;   // wave-uniform
+    const bool careful = exactq;   // wave-uniform
     auto diag_tile = [&](int j, bool first) {
       f32x16 s;
 #pragma unroll
@@ -635,14 +730,14 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       float mx = s[0];   // finite: the sub-tile's first key is admissible for every row
 #pragma unroll
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-      mx = xhalf_max(mx);
+      mx = xhalf_max(mx) * cm;   // log2 units
       float alpha = 1.0f;
       if (first) {
         m_ref = mx;
-      } else {
+      } else {   // (behind a sweep the reference is 0: it only ever moves up)
         const float delta = fmaxf(mx - m_ref, 0.f);
         if (__any(delta > 0.f)) {
-          alpha = __builtin_amdgcn_exp2f(-delta * c);
+          alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -650,11 +745,11 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           m_ref += delta;
         }
       }
-      nmc = -m_ref * c;
+      nmc = -m_ref;
       float rs = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nmc));
+        s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], cm, nmc));
         rs += s[i];
       }
       l_run = l_run * alpha + rs;
@@ -685,19 +780,32 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   }
 
   if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
-  const float l_tot = xhalf_sum(l_run);
+  float l_tot = xhalf_sum(l_run);
+  if constexpr (PRE) {   // a row sum outside [2^-96, 2^96] (or NaN): exp2(S') over- or underflowed somewhere in the wave's rows
+    if (__any(!(l_tot >= 0x1p-96f && l_tot <= 0x1p96f))) {
+      const uint32_t kv_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+      fwd_redo_rows<D>(qrs, make_rsrc(k + base, kv_bytes), make_rsrc(v + base, kv_bytes), qrow, q0, ld, N, CDIAG, c, r, h, acc_o,
+                       m_ref, l_run);
+      l_tot = xhalf_sum(l_run);
+    }
+  }
   const float inv = 1.0f / l_tot;
-  if (qvalid) {
-    float* orow = o + base + (size_t)qrow * ld;
+  // (the output addresses are formed HERE from opaque copies: computed before the loop, hipcc keeps the 64-bit row pointers live
+  // through the pipeline, and the causal d = 64 build, which sits at its 128 registers, spills them around the loop)
+  int qr = qrow, hh = h;
+  asm volatile("" : "+v"(qr), "+v"(hh));
+  if (qr < N) {
+    float* orow = o + base + (size_t)qr * ld;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 val = {acc_o[dt][4 * g] * inv, acc_o[dt][4 * g + 1] * inv, acc_o[dt][4 * g + 2] * inv,
                      acc_o[dt][4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = val;
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * hh) = val;
       }
-    if (h == 0) aux_l[(size_t)bh * N + qrow] = m_ref * tau + __logf(l_tot);
+    if (hh == 0)
+      aux_l[(size_t)bh * N + qr] = PRE ? (m_ref + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f : m_ref * tau + __logf(l_tot);
   }
   if constexpr (DIAG == 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -77,7 +77,7 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m,
                   int batch, int N, int d, int causal, int variant, int dtype, void* stream);
 
-/* Bytes of scratch fa_mi355x_bwd needs: 2 * batch * N floats (-L/tau and -rowsum(dO*O)) and, for shapes the one-pass
+/* Bytes of scratch fa_mi355x_bwd needs: 3 * batch * N floats (-L/tau, -rowsum(dO*O), -L*log2(e)) and, for shapes the one-pass
  * backward takes (d = 64, N a multiple of 256), its flags and running dQ tiles (at most 32 MiB + 16.25 KiB).  Every
  * backward entry point below expects a workspace of at least this size. */
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
@@ -136,6 +136,14 @@ int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, fl
 int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
                      float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
                      int causal, int variant, int dtype, int stages, const int* opts, int nopts, void* stream);
+
+/* Which kernels would a call launch, in order?  Runs the library's own dispatch code with the launches skipped (no HIP call, works
+ * without a GPU except for launch-size rules that read the CU count: 256 is assumed then) and writes the kernel names, separated by
+ * ';', to out[0..n-1] (NUL terminated), e.g. "bwd_dq_slot_kernel;bwd_dkdv_slot_kernel".  stages = 0: the forward (fa_mi355x_fwd_ex);
+ * otherwise the backward stage mask of fa_mi355x_bwd_ex.  A backward plan without "bwd_prep_kernel" means the dQ launch does the
+ * preprocess (and therefore runs first).  bench.py labels its per-kernel timings and its roofline from this. */
+int fa_mi355x_plan(int batch, int N, int d, int causal, int variant, int dtype, int stages, const int* opts, int nopts, char* out,
+                   size_t n);
 
 /* The same two operations on the layout the projection writes: SURVEY.md row f1.  minitorch's MultiHeadAttention
  * produces q, k, v as (B, N, H, d) views and then pays permute(0,2,1,3).contiguous() for each of them, and the

@@ -140,10 +140,11 @@ def test_argument_validation_without_gpu(built):
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)
     assert core.fa_mi355x_version().decode().startswith("flash_attn_mi355x")
-    assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 128) == 2 * 64 * 4096 * 4
-    assert core.fa_mi355x_bwd_workspace_bytes(64, 4100, 64) == 2 * 64 * 4100 * 4      # not a one-pass shape
+    # three row-constant vectors: -L/tau, -rowsum(dO*O), -L*log2(e)
+    assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 128) == 3 * 64 * 4096 * 4
+    assert core.fa_mi355x_bwd_workspace_bytes(64, 4100, 64) == 3 * 64 * 4100 * 4      # not a one-pass shape
     ws = core.fa_mi355x_bwd_workspace_bytes(64, 4096, 64)                              # + flags, pages and running dQ tiles
-    assert 2 * 64 * 4096 * 4 + 16 * 4096 * 256 <= ws <= 2 * 64 * 4096 * 4 + 33 * 2**20
+    assert 3 * 64 * 4096 * 4 + 16 * 4096 * 256 <= ws <= 3 * 64 * 4096 * 4 + 33 * 2**20
     assert core.fa_mi355x_bwd_workspace_bytes(0, 4096, 64) == 0
     # per-call options: diagnostic values are rejected by the product library before any HIP call
     bad = (ctypes.c_int * 3)(93, 0, 0)

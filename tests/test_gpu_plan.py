@@ -1,0 +1,50 @@
+"""The kernel plan (fa_mi355x_plan) is the library's own dispatch code with the launches skipped; bench.py labels its per-kernel
+timings and its roofline from it (bench.stage_plan).  Checked here on the GPU box (the launch-size rules read the CU count): the plan
+of the three shapes the bench line reports, and that bench.py's stage list is built from exactly those names."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CASES = [
+    # (BH, N, d, causal, dtype): forward, whole backward
+    ((64, 4096, 64, False, "bf16"), ["fwd_slot_kernel"], ["bwd_dq_slot_kernel", "bwd_dkdv_slot_kernel"]),      # metric shape M
+    ((64, 4096, 64, True, "bf16"), ["fwd_slot_kernel"], ["bwd_dq_slot_kernel", "bwd_dkdv_slot_kernel"]),       # M under the causal mask
+    ((256, 4096, 128, False, "bf16"), ["fwd_slot_kernel"], ["bwd_dq_kernel", "bwd_dkdv_kernel"]),              # configs[3]
+]
+
+
+@pytest.mark.parametrize("shape,fwd_names,bwd_names", CASES)
+def test_plan_matches_what_bench_times(shape, fwd_names, bwd_names):
+    import torch
+    import bench
+    from flash_attention_minitorch_amd import _lib, device_ops
+    assert torch.cuda.is_available()
+    BH, N, d, causal, dtype = shape
+    dt = _lib.FA_DTYPE_BF16 if dtype == "bf16" else _lib.FA_DTYPE_F32
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0) == fwd_names
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_ALL) == bwd_names
+    stages, k_fwd, k_dq, k_dkdv = bench.stage_plan(device_ops, BH, N, d, causal, dtype, None, lambda: None, lambda s=7: None)
+    assert [n for n, _ in stages] == fwd_names + bwd_names   # no preprocess kernel: the dQ launch does it and runs first
+    assert (k_fwd, k_dq, k_dkdv) == (fwd_names[0], bwd_names[0], bwd_names[1])
+    # stage-split calls name the same kernels (plus the preprocess kernel when dQ is not in the call)
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_DKDV) == [bwd_names[1]]
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_PREP) == ["bwd_prep_kernel"]
+
+
+def test_plan_of_option_and_feature_paths():
+    from flash_attention_minitorch_amd import _lib, device_ops
+    bf, fa2 = _lib.FA_DTYPE_BF16, _lib.FA_VARIANT_FA2
+    # the phased kernels (fp32 scaling) on request
+    assert _lib.plan(64, 4096, 64, False, fa2, bf, 0, device_ops.OPTS_EXACT_SCALE) == ["fwd_kernel"]
+    assert _lib.plan(64, 4096, 64, False, fa2, bf, 7, device_ops.OPTS_EXACT_SCALE) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
+    # a ragged causal launch: phased kernels, each followed by its split-operand launch for the rows with few keys
+    assert _lib.plan(2, 200, 128, True, fa2, bf, 0) == ["fwd_kernel", "fwd_kernel"]
+    # fp32 (the reference's own dtype)
+    assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, _lib.FA_DTYPE_F32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]

@@ -29,6 +29,51 @@ def vanilla_fw_bw(q, k, v, do, causal):
     return o.detach(), qq.grad, kk.grad, vv.grad
 
 
+_FUSED_KIND = [None]
+
+
+def _fused_mask_softmax(s, pad_mask_bool):
+    """softmax(s + padding mask) over the last axis as ONE kernel where torch-ROCm has one (aten::_masked_softmax, the fused
+    mask + softmax of nn.MultiheadAttention's fast path); otherwise mask fill + softmax.  Forward-only calls pass the (B, N)
+    key-padding mask (mask_type 1); under autograd the op's backward wants a mask of the scores' own shape (mask_type 2)."""
+    if _FUSED_KIND[0] in (None, "aten::_masked_softmax"):
+        try:
+            if s.requires_grad:
+                full = pad_mask_bool[:, None, None, :].expand(s.shape).contiguous()
+                p = torch._masked_softmax(s, full, -1, 2)
+            else:
+                p = torch._masked_softmax(s, pad_mask_bool, -1, 1)
+            _FUSED_KIND[0] = "aten::_masked_softmax"
+            return p
+        except Exception:
+            _FUSED_KIND[0] = "torch.softmax(masked_fill(s)): no usable fused masked softmax in this torch build"
+    return torch.softmax(s.masked_fill(pad_mask_bool[:, None, None, :], float("-inf")), dim=-1)
+
+
+def fused_softmax_kind():
+    return _FUSED_KIND[0] or "not run"
+
+
+def fused_softmax_attention(q, k, v, causal):
+    """The reference's use_fused_kernel path (minitorch/modules_transfomer.py:131-136): ((q @ kT) / sqrt(d) + M).attn_softmax(mask) @ v
+    with the scores materialised, M the causal mask (when causal) and `mask` a [B, 1, 1, N] padding mask that is all zeros there.
+    q, k, v: (B, H, N, d)."""
+    B, H, n, d = q.shape
+    s = torch.matmul(q, k.transpose(-1, -2)).float() * (d ** -0.5)
+    if causal:
+        s = s + causal_mask(n, q.device)
+    pad = torch.zeros((B, n), dtype=torch.bool, device=q.device)
+    p = _fused_mask_softmax(s, pad)
+    return torch.matmul(p.to(v.dtype), v)
+
+
+def fused_softmax_fw_bw(q, k, v, do, causal):
+    qq, kk, vv = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    o = fused_softmax_attention(qq, kk, vv, causal)
+    o.backward(do.to(o.dtype))
+    return o.detach(), qq.grad, kk.grad, vv.grad
+
+
 def vanilla_breakdown_ms(q, k, v, causal=True, iters=5):
     """Per-phase time of the vanilla forward, the phases of the reference's breakdown harness
     (kernel_tests/test_flashattn_breakdown.py:44-66): qk = (q @ kT) / sqrt(d); mask = build the causal mask and add it;
