@@ -80,7 +80,9 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
   if (nopts < 0 || nopts > 8 || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
   for (int i = 0; i < nopts; ++i) t.v[i] = opts[i];
 #ifndef FA_DIAG
-  static const int allowed[8][7] = {{0, 1, 2, 3, 4, 5, -1}, {0, 2, 3, 6, -1}, {0, 1, 2, 3, 4, -1}, {0, 1, -1}, {0, 1, 2, -1}, {0, 1, -1}, {0, 1, -1}, {0, 1, 2, -1}};
+  // (round 3 library diet: the values that lost their A/B and had no test -- opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1,
+  // opts[4] = 2 (the one-pass backward), opts[6] = 1 -- exist in the diagnostic build only, together with their kernels)
+  static const int allowed[8][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1}};
   for (int i = 0; i < 8; ++i) {
     bool ok = false;
     for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
@@ -90,19 +92,23 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
   return FA_OK;
 }
 
-// ---- workspace of the one-pass backward (bwd_fused_kernel) ---------------------------------------------------------
-// [ -L/tau : rows floats ][ -delta : rows floats ] (pad to 256 B) [ control: 256 B, word 0 = error ][ flags: FUSED_FLAG_BYTES ]
+// ---- workspace of the one-pass backward (bwd_fused_kernel; diagnostic build only since round 3) --------------------------
+// [ -L/tau | -delta | -L*log2e : 3 * rows floats ] (pad to 256 B) [ control: 256 B, word 0 = error ][ flags: FUSED_FLAG_BYTES ]
 // [ zero page 2 KiB | dummy page 2 KiB ][ running dQ tiles: ngroups * N * 64 floats ]
-constexpr size_t FUSED_CTL_BYTES = fa::FUSED_FLAG0, FUSED_FLAG_BYTES = fa::FUSED_FLAG_BYTES;
-constexpr int FUSED_MAX_CUS = 512;   // sizing bound only (flags: 4 * CUs words; slabs: CUs * 64 KiB)
 inline size_t align256z(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int WS_VECS = 3;   // row-constant vectors at the head of the backward workspace: -L/tau, -delta, -L*log2(e)
+#ifdef FA_DIAG
+constexpr size_t FUSED_CTL_BYTES = fa::FUSED_FLAG0, FUSED_FLAG_BYTES = fa::FUSED_FLAG_BYTES;
+constexpr int FUSED_MAX_CUS = 512;   // sizing bound only (flags: 4 * CUs words; slabs: CUs * 64 KiB)
 inline bool fused_shape(int N, int d) { return d == 64 && N >= 256 && N % 256 == 0 && N / 256 <= FUSED_MAX_CUS; }
 inline size_t fused_extra_bytes(int batch, int N, int d) {
   if (!fused_shape(N, d)) return 0;
   const size_t groups = (size_t)std::min(batch, std::max(1, FUSED_MAX_CUS / (N / 256)));
   return FUSED_CTL_BYTES + FUSED_FLAG_BYTES + fa::FUSED_PAGES + groups * (size_t)N * 64 * sizeof(float);
 }
+#else
+inline size_t fused_extra_bytes(int, int, int) { return 0; }   // the product library runs the two-kernel backward only
+#endif
 int device_cus() {   // compute units of the current device (cached per device; any thread)
   static std::mutex mu;
   static int cus[64];
@@ -204,18 +210,25 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
-      if (whole && tun.v[1] != 6 && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
+#ifdef FA_DIAG
+      constexpr bool diag_stk = true;    // option 1 = 6: the 128-key-stage build of the d = 64 kernel (A/B)
+#else
+      constexpr bool diag_stk = false;
+#endif
+      if (whole && (tun.v[1] != 6 || !diag_stk) && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)
         FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
-      if (whole) {
-        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
-                           (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
-        FA_HIP_TRY(hipGetLastError());
-        return FA_OK;
+      if constexpr (D == 128 || diag_stk) {
+        if (whole) {
+          FA_LAUNCH((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+                             (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
+          FA_HIP_TRY(hipGetLastError());
+          return FA_OK;
+        }
       }
       if constexpr (D == 64) {   // ragged N / forced causal: the variant with masked periods (d = 128 takes the phased kernel)
         FA_LAUNCH((fa::fwd_slot_kernel<T, D, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
@@ -326,11 +339,8 @@ int dq_launch(const void* q, const void* k, const void* v, const void* dout, con
   } else if (BF && (N < 64 || only_qb >= 0 || (causal && care_main))) {
     FA_DQ_LAUNCH(0, BF, nblk, only_qb);
   } else {
-    if (prep)
-      FA_LAUNCH((fa::bwd_dq_kernel<T, D, BN, 0, 4, false, true>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q,
-                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb, *prep);
-    else
-      FA_DQ_LAUNCH(0, false, nblk, only_qb);
+    FA_LAUNCH((fa::bwd_dq_kernel<T, D, BN, 0, 4, false>), dim3(batch * nblk), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+              (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, only_qb, prep ? *prep : fa::DqPrep{});
     if (BF && causal)   // rows 0..63 again with split operands
       FA_LAUNCH((fa::bwd_dq_kernel<T, D, BN, 0, 4, BF>), dim3(batch), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
                          (const T*)dout, nlc, delta, dq, N, nqb, batch, lay1, causal, tau, 0, fa::DqPrep{});
@@ -351,19 +361,11 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
   if (DIAG == 0 && causal && N % 256 == 0) {   // causal build: unmasked sweep + the diagonal block per wave; one block per workgroup,
     // longest first across all heads (paired: blocks p and nqb-1-p in one workgroup)
     const dim3 grid(paired ? batch * ((nqb + 1) / 2) : batch * nqb);
-    if (prep)
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
-                         (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, *prep);
-    else
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
-                         (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, fa::DqPrep{});
+    FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+              (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, prep ? *prep : fa::DqPrep{});
   } else if (DIAG == 0 && !causal && N % 128 == 0) {   // no sub-tile needs a mask: the build without masked period variants
-    if (prep)
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
-                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, *prep);
-    else
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
-                         (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, fa::DqPrep{});
+    FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+              (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, prep ? *prep : fa::DqPrep{});
   } else {
     FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, DIAG>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, fa::DqPrep{});
@@ -395,28 +397,30 @@ int dq_stage(const void* q, const void* k, const void* v, const void* dout, cons
              int N, fa::Layout lay, int causal, float tau, hipStream_t st, const Tun& tun, const fa::DqPrep* prep) {
   int rc;
   if constexpr (sizeof(T) == 2 && D == 128) {
-    if (tun.v[2] == 1)
+#ifdef FA_DIAG
+    if (tun.v[2] == 1)   // 64-key tiles (A/B)
       rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep,
                           tun.v[7] == 2 || (tun.v[7] == 0 && sizeof(T) == 2 && D == 32));
-    else if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr || N < 64)   // 4 waves x 32 queries, two workgroups per CU
+    else
+#endif
+    if (tun.v[2] == 4 || causal || lay.kmask || lay.drop_thr || N < 64)   // 4 waves x 32 queries, two workgroups per CU
       rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep,
                           tun.v[7] == 2 || (tun.v[7] == 0 && sizeof(T) == 2 && D == 32));
     else {   // non-causal default: 8 waves x 32 queries, one workgroup per CU (each staged K / V tile feeds twice the waves)
       const int nqb = (N + 255) / 256;
-      if (prep)
-        FA_LAUNCH((fa::bwd_dq_kernel<T, D, 32, 0, 8, false, true>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
-                           (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, *prep);
-      else
-        FA_LAUNCH((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
-                           (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, fa::DqPrep{});
+      FA_LAUNCH((fa::bwd_dq_kernel<T, D, 32, 0, 8>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+                (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, -1, prep ? *prep : fa::DqPrep{});
       FA_HIP_TRY(hipGetLastError());
       rc = FA_OK;
     }
   } else if constexpr (sizeof(T) == 2 && D == 64) {   // d = 64: slot-interleaved three-deep pipeline (default)
-    if (tun.v[2] == 1)
+#ifdef FA_DIAG
+    if (tun.v[2] == 1)   // phased kernel on 64-key tiles (A/B)
       rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep,
                           tun.v[7] == 2 || (tun.v[7] == 0 && sizeof(T) == 2 && D == 32));
-    else if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || N < 64 ||
+    else
+#endif
+    if (tun.v[2] == 2 || lay.kmask || lay.drop_thr || N < 64 ||
              (causal && tun.v[2] != 3 && !(N % 256 == 0 && batch * (N / 256) >= 128)))
       // key mask and dropout live in the phased kernel, which is also 1 % faster than the slot build WITH masked periods under
       // the causal mask (tuning key 2 = 3 forces the slot kernel).  Causal launches with N a multiple of 256 take the causal slot
@@ -436,10 +440,12 @@ int dq_stage(const void* q, const void* k, const void* v, const void* dout, cons
       if (!rc && causal && N % 256 != 0) rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, 0);
     }
   } else if constexpr (sizeof(T) == 2) {   // d = 32: 32-key tiles run 3 waves/SIMD, measured 2 % faster
+#ifdef FA_DIAG
     if (tun.v[2] == 1)
       rc = dq_launch<T, D, 64>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep,
                           tun.v[7] == 2 || (tun.v[7] == 0 && sizeof(T) == 2 && D == 32));
     else
+#endif
       rc = dq_launch<T, D, 32>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, -1, 0, prep,
                           tun.v[7] == 2 || (tun.v[7] == 0 && sizeof(T) == 2 && D == 32));
   } else {
@@ -469,7 +475,10 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     const int rc = dq_stage<T, D>(q, k, v, dout, nlc, delta, dq, batch, N, lay, causal, tau, st, tun, &pa);
     if (rc) return rc;
   }
+#ifdef FA_DIAG
   if constexpr (sizeof(T) == 2 && D == 64) {
+    // DIAGNOSTIC BUILD ONLY since round 3 (it lost its A/B at every measured size once the two-kernel path dropped its per-score
+    // scale instruction, and it is the one kernel with scratch and a persistent-grid spin protocol): tools/check_fused.py.
     // One pass for dQ, dK, dV (five products instead of seven): non-causal, N a multiple of 256, all members of a head's
     // hand-off chain resident (N / 256 workgroups of one per CU).  Opt-in (option 4 = 2): measured 3-8 % SLOWER than the two-kernel
     // backward up to N = 8192 and 3 % faster at N = 16384 (profiles/README.md, round 2), so the default stays two kernels.
@@ -488,7 +497,6 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 #define FA_FUSED_LAUNCH(ABL)                                                                                              \
   FA_LAUNCH((fa::bwd_fused_kernel<T, 64, ABL>), dim3(grid), dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, \
                      (const T*)dout, nlc, delta, dq, dk, dv, hand, N, nkb, batch, ngroups, xcdmap, lay, tau)
-#ifdef FA_DIAG
       switch (tun.v[5]) {   // timing ablations (wrong results) and phase stamps: see bwd_fused_kernel
         case 1: FA_FUSED_LAUNCH(1); break;
         case 2: FA_FUSED_LAUNCH(2); break;
@@ -505,25 +513,26 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         case 384: FA_FUSED_LAUNCH(384); break;
         default: FA_FUSED_LAUNCH(0); break;
       }
-#else
-      FA_FUSED_LAUNCH(0);
-#endif
 #undef FA_FUSED_LAUNCH
       FA_HIP_TRY(hipGetLastError());
       return FA_OK;
     }
   }
+#endif   // FA_DIAG: one-pass backward
   if (stages & FA_BWD_STAGE_DKDV) {
     int rc;
     if constexpr (sizeof(T) == 2 && D <= 64) {
       // measured at B=8,H=8,N=4096,d=64 (ms, one device, profiles/README.md): 8 waves x 32 keys, 128-query stages,
       // software-pipelined sub-slices 0.505; not pipelined 0.514; 64-query stages 0.519; 256-query 0.525;
       // 4 waves x 32 keys (two workgroups per CU) 0.521; 4 waves x 64 keys (one wave per SIMD) 0.559
-      if (tun.v[0] == 1)
+#ifdef FA_DIAG
+      if (tun.v[0] == 1)   // the geometries that lost their A/B (not pipelined; 4 waves x 64 keys)
         rc = dkdv_launch<T, D, 32, 8, 128, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (tun.v[0] == 2)
         rc = dkdv_launch<T, D, 64, 4, 32, 1>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (tun.v[0] == 4 || D != 64)   // compiler-interleaved software pipeline (the d = 32 default)
+      else
+#endif
+      if (tun.v[0] == 4 || D != 64)   // compiler-interleaved software pipeline (the d = 32 default)
         rc = dkdv_launch<T, D, 32, 8, 128, 0>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
 #ifdef FA_DIAG
       else if (tun.v[0] == 13 && D == 64)   // slot path on register staging instead of LDS-DMA (A/B)
@@ -576,11 +585,14 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
         rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st, tun.v[6] == 0 ? 1 : 0);
     } else if constexpr (sizeof(T) == 2) {
+#ifdef FA_DIAG
       if (tun.v[0] == 1)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (tun.v[0] == 2)
         rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (tun.v[0] == 5 || lay.drop_thr)   // two 128-key workgroups per CU (4 waves each); the dropout build needs its registers
+      else
+#endif
+      if (tun.v[0] == 5 || lay.drop_thr)   // two 128-key workgroups per CU (4 waves each); the dropout build needs its registers
         rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else   // d = 128 default: 8 waves x 32 keys, one 256-key workgroup per CU (half the Q / dO staging per MFMA): 3.64 vs 3.92 ms
         rc = dkdv_launch<T, D, 32, 8, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st, 0, tun.v[7] != 1);
@@ -589,14 +601,17 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       // (launch bound) keeps it under 256 (tuning key 0 = 1: the unconstrained build)
       if (tun.v[0] == 1 || lay.drop_thr)
         rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else if (tun.v[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves
+#ifdef FA_DIAG
+      else if (tun.v[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves (A/B: 2 % slower)
         const int nkb = (N + 255) / 256;
         FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, 32, 8, 32, 0, false, 2>), dim3(batch * nkb), dim3(512), 0, st,
                            (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dk, dv, N, nkb, batch, lay,
                            causal, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
-      } else {
+      }
+#endif
+      else {
         const int nkb = (N + 127) / 128;
         // causal: longest block first across a chunk of heads instead of head by head: 0.57 vs 0.80 ms at the reference's timing-harness
         // shape (B = 8, H = 8, N = 2048, fp32), bitwise the same (option 7 = 1: head by head)
@@ -742,6 +757,7 @@ struct Pinned {
 struct HostPipe {
   hipStream_t up = nullptr, down = nullptr;
   std::vector<hipEvent_t> ev;
+  int dev = -1;   // streams and events belong to the device that was current when they were created (like the arena)
   hipEvent_t event(size_t i) {
     while (ev.size() <= i) {
       hipEvent_t e;
@@ -750,9 +766,26 @@ struct HostPipe {
     }
     return ev[i];
   }
+  void release() {   // on the device they were created on
+    if (dev < 0) return;
+    int cur = 0;
+    FA_HOST_TRY(hipGetDevice(&cur));
+    if (cur != dev) FA_HOST_TRY(hipSetDevice(dev));
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+    if (up) (void)hipStreamDestroy(up);
+    if (down) (void)hipStreamDestroy(down);
+    up = down = nullptr;
+    if (cur != dev) FA_HOST_TRY(hipSetDevice(cur));
+    dev = -1;
+  }
   void init() {
+    int cur = 0;
+    FA_HOST_TRY(hipGetDevice(&cur));
+    if (dev >= 0 && dev != cur) release();   // the caller moved to another device since the last host-pointer call
     if (!up) FA_HOST_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
     if (!down) FA_HOST_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+    dev = cur;
   }
 };
 HostPipe g_pipe;   // guarded by g_pool_mu, like the arena
@@ -809,37 +842,41 @@ int fa_mi355x_measure_mfma_peak(double min_ms, double* tflops, double* clock_ghz
   FA_HIP_TRY(hipGetDevice(&dev));
   FA_HIP_TRY(hipGetDeviceProperties(&prop, dev));
   const int blocks = prop.multiProcessorCount, iters = 4000;
-  float* sink = nullptr;
-  unsigned long long* stamps = nullptr;
-  FA_HIP_TRY(hipMalloc(&sink, (size_t)blocks * 512 * sizeof(float)));
-  FA_HIP_TRY(hipMalloc(&stamps, (size_t)blocks * 16 * sizeof(unsigned long long)));
-  hipEvent_t e0, e1;
-  FA_HIP_TRY(hipEventCreate(&e0));
-  FA_HIP_TRY(hipEventCreate(&e1));
+  struct Res {   // released on every exit
+    float* sink = nullptr;
+    unsigned long long* stamps = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Res() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (sink) (void)hipFree(sink);
+      if (stamps) (void)hipFree(stamps);
+    }
+  } r;
+  FA_HIP_TRY(hipMalloc(&r.sink, (size_t)blocks * 512 * sizeof(float)));
+  FA_HIP_TRY(hipMalloc(&r.stamps, (size_t)blocks * 16 * sizeof(unsigned long long)));
+  FA_HIP_TRY(hipEventCreate(&r.e0));
+  FA_HIP_TRY(hipEventCreate(&r.e1));
   // back-to-back launches until min_ms have passed (the clock settles under load); the last batch is the one reported
   double ms_per = 0.0, spent = 0.0;
   int reps = 4;
   for (int round = 0; round < 6 && spent < min_ms; ++round) {
-    FA_HIP_TRY(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(fa::mfma_peak_kernel, dim3(blocks), dim3(512), 0, st, sink, stamps, iters);
-    FA_HIP_TRY(hipEventRecord(e1, st));
-    FA_HIP_TRY(hipEventSynchronize(e1));
+    FA_HIP_TRY(hipEventRecord(r.e0, st));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(fa::mfma_peak_kernel, dim3(blocks), dim3(512), 0, st, r.sink, r.stamps, iters);
+    FA_HIP_TRY(hipEventRecord(r.e1, st));
+    FA_HIP_TRY(hipEventSynchronize(r.e1));
     float ms = 0.f;
-    FA_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    FA_HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
     ms_per = ms / reps;
     spent += ms;
     reps *= 2;
   }
   std::vector<unsigned long long> h((size_t)blocks * 16);
-  FA_HIP_TRY(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  FA_HIP_TRY(hipMemcpy(h.data(), r.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   double cyc = 0, ticks = 0;
   for (size_t i = 0; i + 1 < h.size(); i += 2) { cyc += (double)h[i]; ticks += (double)h[i + 1]; }
   *clock_ghz = ticks > 0 ? cyc / ticks * 0.1 : 0.0;
   *tflops = (double)blocks * 8.0 * iters * 8.0 * (2.0 * 32 * 32 * 16) / (ms_per * 1e-3) / 1e12;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(sink);
-  hipFree(stamps);
   return FA_OK;
 }
 
@@ -905,6 +942,28 @@ int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* o
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
   return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, batch, N, d, d, bhnd(N, d),
                       causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream, tun);
+}
+
+int fa_mi355x_fwd_padded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
+                         int dp, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m)) return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(dp) || d > dp) return set_err(FA_ERR_UNSUPPORTED_D, "padded row length dp must be 32, 64 or 128 and >= d");
+  return fwd_dispatch(q, k, v, out, l, m, batch, N, d, dp, bhnd(N, dp), causal ? 1 : 0, variant, dtype, (hipStream_t)stream);
+}
+
+int fa_mi355x_bwd_padded(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                         float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
+                         int dp, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (int rc = check_common(batch, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(dp) || d > dp) return set_err(FA_ERR_UNSUPPORTED_D, "padded row length dp must be 32, 64 or 128 and >= d");
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, batch, N, d, dp, bhnd(N, dp),
+                      causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream);
 }
 
 int fa_mi355x_fwd_layout(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H,

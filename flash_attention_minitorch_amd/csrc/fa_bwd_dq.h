@@ -5,7 +5,8 @@
 
 namespace fa {
 
-// FPREP = true (both dQ kernels): the launch also does the backward's preprocess (bwd_prep_kernel) for its own query rows: every wave forms
+// pa.o != nullptr (both dQ kernels, plain builds; a run-time switch since round 3, one build instead of two): the launch also does the
+// backward's preprocess (bwd_prep_kernel) for its own query rows: every wave forms
 // -delta = -rowsum(dO * O) and -L / tau of its 32 rows from the forward's O and side outputs (its dO fragments are in registers
 // anyway; the query is on the lane), uses them, and stores them to the workspace, from where the dK/dV kernel, launched AFTER this
 // one, takes them as it always did.  One launch and one pass over dO less per backward (the preprocess kernel: 0.020 ms of the
@@ -53,12 +54,12 @@ FA_DEV void dq_prep_rows(const DqPrep& pa, const typename Atom<T>::frag (&dof)[K
 // Backward dQ: same shape as the forward (NWQ waves x 32 query rows, K/V tiles of BN keys through LDS).  NWQ = 4 by
 // default; the bf16 d = 128 launch uses 8 (one workgroup per CU sharing each staged tile between twice the waves).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4, bool CARE = false, bool FPREP = false>   // CARE: as fwd_kernel's
+template <typename T, int D, int BN, int FEAT = 0, int NWQ = 4, bool CARE = false>   // CARE: as fwd_kernel's
 __global__ void __launch_bounds__(64 * NWQ)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
               int BH, Layout lay, int causal, float tau, int only_qb = -1, DqPrep pa = DqPrep{}) {
-  static_assert(!FPREP || (FEAT == 0 && !CARE), "the preprocess is folded into the plain main build only");
+  constexpr bool CAN_PREP = FEAT == 0 && !CARE;   // the preprocess is folded into the plain main build only (the launcher knows)
   using A = Atom<T>;   // only_qb: as fwd_kernel's
   typedef typename A::frag frag;
   constexpr bool HM = FEAT >= 1, HD = FEAT >= 2;   // key mask (staged as zeros when absent); dropout
@@ -101,7 +102,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
   }
   // this lane's row constants; -delta, in every register, is the accumulator input of the dP^T tiles
   float nlq, ndq;
-  if constexpr (FPREP) {
+  if (CAN_PREP && pa.o != nullptr) {   // (kernel argument: a scalar branch)
     dq_prep_rows<T, KC>(pa, dof, base, bh, N, qrow, ld, h, qvalid, c, nlq, ndq);
   } else {
     nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)
@@ -283,7 +284,7 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles
 // 0..w and masks the last one; rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p
 // share a workgroup (uniform work).
-template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false, bool FPREP = false>
+template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                    const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
@@ -326,7 +327,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     dof[kc] = load_frag_buf<T>(dors, off);
   }
   float nlq, ndq;
-  if constexpr (FPREP) {
+  if (!MASKS && pa.o != nullptr) {   // (kernel argument: a scalar branch; the masked build never folds the preprocess in)
     dq_prep_rows<T, KC>(pa, dof, base, bh, N, qrow, ld, h, qvalid, c, nlq, ndq);
   } else {
     nlq = qvalid ? nlc[(size_t)bh * N + qrow] * c : 0.f;   // -L * log2(e)

@@ -29,5 +29,7 @@
 #include "fa_fwd.h"
 #include "fa_bwd_dkdv.h"
 #include "fa_bwd_dq.h"
-#include "fa_bwd_fused.h"
+#ifdef FA_DIAG
+#include "fa_bwd_fused.h"   // the one-pass backward: diagnostic build only (tools/check_fused.py)
+#endif
 #include "fa_aux.h"

@@ -51,14 +51,45 @@ OPTS_PHASED = (4, 2, 2)          # the round-1 phased kernels instead of the MFM
 # of larger magnitude (scores of tens) the slot kernels' error grows with 2^-9 * sum_d |tau q_d k_d| and this selection keeps the
 # phased kernels' envelope (tests/test_gpu_parity.py::test_large_magnitude_inputs_stay_finite).
 OPTS_EXACT_SCALE = OPTS_PHASED
-OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # dQ inside the key-stationary kernel, ordered hand-off (bf16, d = 64, non-causal, N % 256 == 0)
+OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # DIAGNOSTIC LIBRARY ONLY (tools/check_fused.py): dQ inside the key-stationary kernel, ordered hand-off
+
+
+_NATIVE_D = (32, 64, 128)
+
+
+def _padded_d(d):
+    if d > 128:
+        raise ValueError("head dimension d > 128 is not supported (the reference kernels assert d <= 128, src/flash_attn_fw.cu:43)")
+    return 32 if d <= 32 else (64 if d <= 64 else 128)
+
+
+def _pad_cols(t, dp):
+    """(.., N, d) -> contiguous (.., N, dp) with zero columns d .. dp-1 (what fa_mi355x_*_padded expects)."""
+    return torch.nn.functional.pad(t, (0, dp - t.shape[-1]))
 
 
 def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None):
     """Forward.  Returns (out fp32, l, m): FA-1 -> l = sum exp(s - rowmax), m = rowmax;
-    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*)."""
+    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*).
+    Any head dim d <= 128: d outside {32, 64, 128} is zero-padded to the next of them on the device (tau keeps the caller's d; the
+    reference operator takes any d up to its assert, minitorch/cuda_kernel_ops.py:527-581 / src/flash_attn_fw.cu:43)."""
     bh, n, d = _check_inputs(q, k, v)
     lead = q.shape[:-2]
+    if d not in _NATIVE_D:
+        dp = _padded_d(d)
+        qp, kp, vp = (_pad_cols(t, dp) for t in (q, k, v))
+        outp = torch.empty(lead + (n, dp), dtype=torch.float32, device=q.device)
+        if l is None:
+            l = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
+        if variant == _lib.FA_VARIANT_FA1 and m is None:
+            m = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.core().fa_mi355x_fwd_padded(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(outp), _ptr(l), _ptr(m), bh, n, d, dp,
+                                                    int(bool(causal)), variant, _DTYPES[q.dtype], _stream_ptr()))
+        if out is None:
+            out = outp[..., :d].contiguous()
+        else:
+            out.copy_(outp[..., :d])
+        return out, l, m
     if out is None:
         out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     if l is None:
@@ -79,7 +110,7 @@ def _workspace(bh, n, d, device):
 def bwd_workspace(q):
     """Scratch for the backward of (.., N, d) tensors, sized by the library (fa_mi355x_bwd_workspace_bytes)."""
     n, d = q.shape[-2], q.shape[-1]
-    return _workspace(q.numel() // (n * d), n, d, q.device)
+    return _workspace(q.numel() // (n * d), n, _padded_d(d), q.device)
 
 
 def bwd_status(workspace, q):
@@ -101,6 +132,19 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
     bh, n, d = _check_inputs(q, k, v, out_grad)
     if out.dtype != torch.float32 or out.shape != q.shape or not out.is_contiguous():
         raise ValueError("out must be the forward's contiguous float32 output")
+    if d not in _NATIVE_D:   # any d <= 128: zero-padded columns, see flash_attn_fwd
+        dp = _padded_d(d)
+        qp, kp, vp, op, dop = (_pad_cols(t, dp) for t in (q, k, v, out, out_grad))
+        ws = _workspace(bh, n, dp, q.device)
+        gp = tuple(torch.empty(qp.shape, dtype=torch.float32, device=q.device) for _ in range(3))
+        _lib.check(_lib.core().fa_mi355x_bwd_padded(_ptr(qp), _ptr(kp), _ptr(vp), _ptr(op), _ptr(dop), _ptr(gp[0]), _ptr(gp[1]),
+                                                    _ptr(gp[2]), _ptr(l), _ptr(m), _ptr(ws), bh, n, d, dp, int(bool(causal)),
+                                                    variant, _DTYPES[q.dtype], _stream_ptr()))
+        if grads is None:
+            return tuple(g[..., :d].contiguous() for g in gp)
+        for dst, g in zip(grads, gp):
+            dst.copy_(g[..., :d])
+        return tuple(grads)
     if workspace is None:
         workspace = bwd_workspace(q)
     if grads is None:

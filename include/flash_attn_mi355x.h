@@ -137,6 +137,16 @@ int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* o
                      float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
                      int causal, int variant, int dtype, int stages, const int* opts, int nopts, void* stream);
 
+/* Any head dim d <= 128 on the device path (the reference operator accepts any d up to its assert, src/flash_attn_fw.cu:43; the host
+ * launchers above pad on the fly): q, k, v, out_grad, out and the gradients are [batch][N][dp] with dp in {32, 64, 128}, dp >= d, and
+ * columns d .. dp-1 of q, k, v, out_grad ZERO (zero columns of q / k add nothing to the scores, zero columns of v / out_grad give zero
+ * columns of out / the gradients); tau = 1/sqrt(d) uses the caller's d.  device_ops pads and slices with torch. */
+int fa_mi355x_fwd_padded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
+                         int dp, int causal, int variant, int dtype, void* stream);
+int fa_mi355x_bwd_padded(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                         float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
+                         int dp, int causal, int variant, int dtype, void* stream);
+
 /* Which kernels would a call launch, in order?  Runs the library's own dispatch code with the launches skipped (no HIP call, works
  * without a GPU except for launch-size rules that read the CU count: 256 is assumed then) and writes the kernel names, separated by
  * ';', to out[0..n-1] (NUL terminated), e.g. "bwd_dq_slot_kernel;bwd_dkdv_slot_kernel".  stages = 0: the forward (fa_mi355x_fwd_ex);

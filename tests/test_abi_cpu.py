@@ -37,7 +37,7 @@ def test_header_declares_expected_entry_points():
     syms = _declared_symbols()
     for s in ("launch_flash_attn_fw", "launch_flash_attn_bw", "fa_mi355x_fwd", "fa_mi355x_bwd",
               "fa_mi355x_bwd_workspace_bytes", "fa_mi355x_launch_fw_host", "fa_mi355x_launch_bw_host",
-              "fa_mi355x_bwd_stages", "fa_mi355x_fwd_layout", "fa_mi355x_bwd_layout", "fa_mi355x_fwd_masked", "fa_mi355x_bwd_masked", "fa_mi355x_fwd_dropout", "fa_mi355x_bwd_dropout", "fa_mi355x_last_error", "fa_mi355x_version", "fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex", "fa_mi355x_bwd_status", "fa_mi355x_measure_mfma_peak", "fa_mi355x_probe"):
+              "fa_mi355x_bwd_stages", "fa_mi355x_fwd_layout", "fa_mi355x_bwd_layout", "fa_mi355x_fwd_masked", "fa_mi355x_bwd_masked", "fa_mi355x_fwd_dropout", "fa_mi355x_bwd_dropout", "fa_mi355x_last_error", "fa_mi355x_version", "fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex", "fa_mi355x_bwd_status", "fa_mi355x_measure_mfma_peak", "fa_mi355x_probe", "fa_mi355x_plan", "fa_mi355x_fwd_padded", "fa_mi355x_bwd_padded"):
         assert s in syms
 
 
@@ -98,8 +98,8 @@ def _device_kernels(path):
 
 def test_product_library_has_no_diagnostic_code_and_no_scratch(built):
     """stamp builds, the barrier-less ablation and fa_mi355x_set_tuning live in the FA_DIAG build only, and no
-    kernel of the product library uses scratch memory.  One documented exception: the opt-in one-pass backward keeps <= 16 B per
-    lane for values that are live across (not inside) its sweep loop (csrc/fa_bwd_fused.h; hipcc's allocation, outside the loop)."""
+    kernel of the product library uses scratch memory (round 3: no exception left; the one-pass backward, which kept 8 B per lane,
+    moved to the diagnostic build)."""
     path = built.lib_path("libflash_attn_mi355x.so")
     syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     for s in _declared_symbols(diag=True):
@@ -109,16 +109,14 @@ def test_product_library_has_no_diagnostic_code_and_no_scratch(built):
     assert len(kernels) > 40
     for name, scratch, vgpr in kernels:
         assert vgpr <= 512
-        if "bwd_fused_kernel" in name:
-            assert scratch <= 16, (name, scratch)
-        else:
-            assert scratch == 0, (name, scratch)
+        assert scratch == 0, (name, scratch)
     # template arguments that only diagnostic instantiations carry: DIAG = 1 / 2 of the slot kernels, MODE 9 / 13 / 93 of dK/dV, ABL != 0
     names = " ".join(k[0] for k in kernels)
     assert not re.search(r"bwd_dkdv_kernelI\S*Li(9|13|93)ELb", names)
     assert "bwd_dkdv_slot_kernelIDF16bLi64ELi1E" not in names and "bwd_dq_slot_kernelIDF16bLi64ELi1E" not in names
     assert "bwd_dq_slot_kernelIDF16bLi64ELi2E" not in names
-    assert re.search(r"bwd_fused_kernelIDF16bLi64ELi0E", names) and not re.search(r"bwd_fused_kernelIDF16bLi64ELi[1-9]", names)
+    assert "bwd_fused_kernel" not in names   # the one-pass backward: diagnostic build only since round 3
+    assert len(kernels) < 100, len(kernels)   # round 3 library diet (133 before)
 
 
 def test_diagnostic_library_exports_the_diag_entry_points(built):
@@ -143,8 +141,7 @@ def test_argument_validation_without_gpu(built):
     # three row-constant vectors: -L/tau, -rowsum(dO*O), -L*log2(e)
     assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 128) == 3 * 64 * 4096 * 4
     assert core.fa_mi355x_bwd_workspace_bytes(64, 4100, 64) == 3 * 64 * 4100 * 4      # not a one-pass shape
-    ws = core.fa_mi355x_bwd_workspace_bytes(64, 4096, 64)                              # + flags, pages and running dQ tiles
-    assert 3 * 64 * 4096 * 4 + 16 * 4096 * 256 <= ws <= 3 * 64 * 4096 * 4 + 33 * 2**20
+    assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 64) == 3 * 64 * 4096 * 4
     assert core.fa_mi355x_bwd_workspace_bytes(0, 4096, 64) == 0
     # per-call options: diagnostic values are rejected by the product library before any HIP call
     bad = (ctypes.c_int * 3)(93, 0, 0)

@@ -144,6 +144,36 @@ def test_reference_odd_head_dim_shape(ops):
     assert maxabs(f(dv)[heads], ref["dv"]) < TOL32
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_reference_odd_head_dim_shape_device_resident(dev, dtype):
+    """The same shape (N = 327, d = 34, causal; kernel_tests/test_flashattn_2_fw.py:133-140) through the device-resident operator
+    surface: any d <= 128 is zero-padded to the next of {32, 64, 128} on the device (fa_mi355x_*_padded), tau keeps the caller's d.
+    Also d = 100 (padded to 128) and d = 20 (padded to 32), FA-1 side outputs."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    tol = TOL32 if dtype == "f32" else TOLBF
+    for (BH, N, d, causal, variant) in ((8, 327, 34, True, _lib.FA_VARIANT_FA2), (3, 200, 100, False, _lib.FA_VARIANT_FA1),
+                                        (4, 129, 20, True, _lib.FA_VARIANT_FA2)):
+        rng = np.random.default_rng(133 + d)
+        arrs = [rand_u(rng, (BH, N, d)) for _ in range(4)]
+        if dtype == "bf16":
+            arrs = [oracle.bf16_round(a) for a in arrs]
+        t = [torch.from_numpy(a).to("cuda", tdt) for a in arrs]
+        o, l, m = dev.flash_attn_fwd(*t[:3], causal, variant)
+        dq, dk, dv = dev.flash_attn_bwd(*t[:3], o, t[3], l, m, causal, variant)
+        assert o.shape == (BH, N, d) and dq.shape == (BH, N, d) and o.is_contiguous()
+        ref = oracle_heads(*arrs, causal, range(BH))
+        L = l if variant == _lib.FA_VARIANT_FA2 else m + torch.log(l)
+        for nm, got in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
+            assert maxabs(to_np(got), ref[nm]) < tol, (d, nm, maxabs(to_np(got), ref[nm]))
+    # the autograd contract on an odd head dim
+    q, k, v = (torch.from_numpy(a).to("cuda", tdt).requires_grad_(True) for a in arrs[:3])
+    out = dev.flash_attn2(q, k, v, True)
+    out.backward(torch.from_numpy(arrs[3]).to("cuda"))
+    assert maxabs(to_np(q.grad), ref["dq"]) < (tol if dtype == "f32" else 1e-2)   # (bf16: the gradient is cast to the input dtype)
+
+
 # ---------------------------------------------------------------- BASELINE.json configs[1], configs[2] (fp32, full size)
 def test_c1_fa1_forward_fp32_full(ops):
     rng = np.random.default_rng(1001)
@@ -481,56 +511,18 @@ def test_causal_forward_slot_kernel_d128(dev, N):
     assert maxabs(to_np(o_s), to_np(o_p)) < 1.5 * TOLBF
 
 
-@pytest.mark.parametrize("BH,N", [(1, 256), (3, 512), (5, 768), (2, 2048), (20, 1024)])
-def test_one_pass_backward_matches_oracle_and_two_kernel_path(dev, BH, N):
-    """The opt-in one-pass backward (csrc/fa_bwd_fused.h: dQ formed in the key-stationary kernel, summed across the N/256
-    key-block workgroups of a head by the ordered hand-off; src/flash_attn2_bw.cu:94-247 is the single pass it matches): against
-    the fp64 oracle (1e-3), against the default two-kernel backward, bitwise repeatable, no hand-off timeout.  BH = 20 at
-    N = 1024 makes groups walk several heads (the flags count on across heads); N = 768 has a chain length that does not
-    divide 32 (groups span XCDs)."""
-    import torch
-    rng = np.random.default_rng(9100 + N + BH)
-    d = 64
-    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
-    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
-    o, l, _ = dev.flash_attn_fwd(tq, tk, tv)
-    ws = dev.bwd_workspace(tq)
-    one = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws, opts=dev.OPTS_ONE_PASS_BWD)]
-    assert dev.bwd_status(ws, tq) == 0
-    again = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws, opts=dev.OPTS_ONE_PASS_BWD)]
-    two = [to_np(x) for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws)]
-    heads = range(BH) if BH * N <= 4096 else range(0, BH, max(1, BH // 3))
-    ref = oracle_heads(*arrs, False, heads)
-    for nm, a, b, c in zip(("dq", "dk", "dv"), one, again, two):
-        assert np.all(np.isfinite(a)), nm
-        assert np.array_equal(a, b), nm                       # fixed summation order: bitwise repeatable
-        assert maxabs(a, c) < 0.5 * TOLBF, (nm, maxabs(a, c))  # same arithmetic per element, another summation order
-        assert maxabs(a[list(heads)], ref[nm]) < TOLBF, (nm, maxabs(a[list(heads)], ref[nm]))
-
-
-def test_one_pass_backward_at_metric_shape(dev):
-    """B=8, H=8, N=4096, d=64 (BASELINE.json's metric shape): sampled heads against the oracle, size-independent properties."""
-    import torch
-    BH, N, d = 64, 4096, 64
-    gen = torch.Generator(device="cuda").manual_seed(77)
-    mk = lambda: ((torch.rand((BH, N, d), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
-    tq, tk, tv, tdo = mk(), mk(), mk(), mk()
-    o, l, _ = dev.flash_attn_fwd(tq, tk, tv)
-    ws = dev.bwd_workspace(tq)
-    dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws, opts=dev.OPTS_ONE_PASS_BWD)
-    assert dev.bwd_status(ws, tq) == 0
-    dq2, dk2, dv2 = (x.clone() for x in dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, workspace=ws))
-    for nm, a, b in (("dq", dq, dq2), ("dk", dk, dk2), ("dv", dv, dv2)):
-        assert float((a - b).abs().max()) < 0.5 * TOLBF, nm
-    # sum_q dQ o Q = sum_k dK o K per head (both equal sum dS o S / tau-free identity of the softmax backward)
-    lhs = (dq * tq.float()).sum(dim=(1, 2)).cpu().numpy()
-    rhs = (dk * tk.float()).sum(dim=(1, 2)).cpu().numpy()
-    assert np.max(np.abs(lhs - rhs)) < 2e-2 * max(1.0, float(np.max(np.abs(lhs))))
-    heads = [0, 29, 63]
-    arrs = [to_np(t.float())[heads] for t in (tq, tk, tv, tdo)]
-    ref = oracle_heads(*arrs, False, range(len(heads)))
-    for nm, a in (("dq", dq), ("dk", dk), ("dv", dv)):
-        assert maxabs(to_np(a)[heads], ref[nm]) < TOLBF, nm
+def test_one_pass_backward_in_the_diagnostic_library():
+    """The one-pass backward (csrc/fa_bwd_fused.h: dQ formed in the key-stationary kernel and summed across the key-block workgroups
+    of a head by an ordered hand-off; the reference's single pass, src/flash_attn2_bw.cu:94-247) left the product library in round 3
+    (it lost its A/B at every size and was the one kernel with scratch and a spin protocol) and lives in the diagnostic build.
+    tools/check_fused.py, run as a CHILD process (this process never loads the diagnostic library), checks it against the fp64
+    oracle (1e-3), against the two-kernel backward, bitwise repeatability and the hand-off status word at six shapes incl. B=8, H=8,
+    N=4096."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_fused.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("dtype,d", [("f32", 64), ("bf16", 128), ("bf16", 32)])
@@ -922,8 +914,8 @@ def test_autograd_functions_follow_reference_contract(dev):
 def test_device_path_rejects_bad_input(dev):
     import torch
     from flash_attention_minitorch_amd import _lib
-    q = torch.zeros((2, 16, 34), device="cuda")
-    with pytest.raises(_lib.FlashAttnLibraryError, match="32, 64, 128"):
+    q = torch.zeros((2, 16, 130), device="cuda")
+    with pytest.raises(ValueError, match="d > 128"):   # the reference asserts d <= 128 (src/flash_attn_fw.cu:43)
         dev.flash_attn_fwd(q, q, q)
     with pytest.raises(_lib.FlashAttnLibraryError, match="no CPU fallback"):
         c = torch.zeros((2, 16, 64))
