@@ -30,12 +30,11 @@ def _oracle_bwd(q, k, v, o, do, L, causal):
     return tuple(torch.from_numpy(a.astype(np.float32)) for a in g)
 
 
-def _worker(rank, world, port, bh_total, causal, out_dir):
+def _worker(rank, world, port, bh_total, causal, out_dir, N=24, d=16, chunks=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        N, d = 24, 16
         rng = np.random.default_rng(123)   # every rank draws the full problem, then keeps its slice
         full = [torch.from_numpy(rng.uniform(-1, 1, (bh_total, N, d)).astype(np.float32)) for _ in range(4)]
         b, e = sharded.shard_range(bh_total, rank, world)
@@ -46,8 +45,8 @@ def _worker(rank, world, port, bh_total, causal, out_dir):
                                                       compute_fn=_oracle_bwd)
         assert o.shape == (bh_total, N, d) and L.shape == (bh_total, N)
         # gather hidden under the compute of the next piece: same tensors, bit for bit (falls back when the split is ragged)
-        o2, L2 = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, bh_total, causal, chunks=3 if (e - b) % 3 == 0 else 2,
-                                                            compute_fn=_oracle_fwd)
+        o2, L2 = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, bh_total, causal,
+                                                            chunks=chunks or (3 if (e - b) % 3 == 0 else 2), compute_fn=_oracle_fwd)
         assert torch.equal(o2, o) and torch.equal(L2, L)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), o=o.numpy(), L=L.numpy(), dq=dq.numpy(), dk=dk.numpy(),
                  dv=dv.numpy())
@@ -67,6 +66,22 @@ def test_shard_and_gather_matches_single_process(tmp_path, world, bh_total, caus
         got = np.load(tmp_path / f"rank{r}.npz")
         for name, ref in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
             assert np.max(np.abs(got[name] - ref)) < 1e-5, (r, name)
+
+
+def test_configs4_split_eight_ranks_overlapped_gather(tmp_path):
+    """BASELINE.json configs[4]'s partition: 2048 (batch, head) pairs over 8 ranks = 256 per rank, the forward's gather hidden under the
+    compute in 4 pieces of 64 (what bench.py --config c4 --gpus 8 runs over RCCL), here on gloo with tiny heads (N = 8, d = 8)."""
+    world, bh_total, N, d = 8, 2048, 8, 8
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, bh_total, False, str(tmp_path), N, d, 4), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    q, k, v, do = (rng.uniform(-1, 1, (bh_total, N, d)).astype(np.float32) for _ in range(4))
+    o, L, _, _ = oracle.dense_attention_fw(q, k, v, False)
+    dq, dk, dv = oracle.dense_attention_bw(q, k, v, do, False)
+    for r in (0, 3, 7):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for name, ref in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
+            assert got[name].shape == ref.shape and np.max(np.abs(got[name] - ref)) < 1e-5, (r, name)
 
 
 def test_shard_bounds_are_contiguous_and_balanced():
