@@ -109,6 +109,10 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_bwd_ex.restype = _i
     h.fa_mi355x_bwd_status.argtypes = [_vp, _i, _i, _i, _ip]
     h.fa_mi355x_bwd_status.restype = _i
+    h.fa_mi355x_fwd_scaled.argtypes = [_vp] * 6 + [_i] * 5 + [ctypes.c_float] + [_i] * 3 + [_vp]
+    h.fa_mi355x_fwd_scaled.restype = _i
+    h.fa_mi355x_bwd_scaled.argtypes = [_vp] * 11 + [_i] * 5 + [ctypes.c_float] + [_i] * 3 + [_vp]
+    h.fa_mi355x_bwd_scaled.restype = _i
     h.fa_mi355x_fwd_padded.argtypes = [_vp] * 6 + [_i] * 7 + [_vp]
     h.fa_mi355x_fwd_padded.restype = _i
     h.fa_mi355x_bwd_padded.argtypes = [_vp] * 11 + [_i] * 7 + [_vp]

@@ -653,16 +653,17 @@ fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullp
 fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u, 0}; }
 
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
-                 int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st, const Tun& tun = default_tun()) {
-  const float tau = sqrtf(1.0f / (float)d);
+                 int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st, const Tun& tun = default_tun(),
+                 float scale = 0.f) {
+  const float tau = scale > 0.f ? scale : sqrtf(1.0f / (float)d);   // (scale: fa_mi355x_*_scaled; the reference has sqrt(1/d) only)
   lay.young_prio = tun.v[3];
   FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st, tun);
 }
 
 int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
                  float* dv, const float* l, const float* m, float* ws, int batch, int N, int d, int dp, fa::Layout lay,
-                 int causal, int variant, int dtype, int stages, hipStream_t st, const Tun& tun = default_tun()) {
-  const float tau = sqrtf(1.0f / (float)d);
+                 int causal, int variant, int dtype, int stages, hipStream_t st, const Tun& tun = default_tun(), float scale = 0.f) {
+  const float tau = scale > 0.f ? scale : sqrtf(1.0f / (float)d);
   lay.young_prio = tun.v[3];
   FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, lay, causal, variant, tau, stages, st, tun);
 }
@@ -942,6 +943,39 @@ int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* o
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
   return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, batch, N, d, d, bhnd(N, d),
                       causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream, tun);
+}
+
+int fa_mi355x_fwd_scaled(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H, int N, int d,
+                         int layout, float softmax_scale, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m)) return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if (!(softmax_scale > 0.f) || !std::isfinite(softmax_scale)) return set_err(FA_ERR_BAD_ARG, "softmax_scale must be positive and finite");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  return fwd_dispatch(q, k, v, out, l, m, B * H, N, d, d, lay, causal ? 1 : 0, variant, dtype, (hipStream_t)stream, default_tun(),
+                      softmax_scale);
+}
+
+int fa_mi355x_bwd_scaled(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                         float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int B, int H, int N, int d,
+                         int layout, float softmax_scale, int causal, int variant, int dtype, void* stream) {
+  g_err[0] = 0;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if (!(softmax_scale > 0.f) || !std::isfinite(softmax_scale)) return set_err(FA_ERR_BAD_ARG, "softmax_scale must be positive and finite");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
+                      causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream, default_tun(), softmax_scale);
 }
 
 int fa_mi355x_fwd_padded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,

@@ -158,10 +158,12 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
     return dq, dk, dv
 
 
-def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2):
+def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None):
     """Forward on (B, N, H, d) tensors -- the layout minitorch's projection writes before its
     permute(0,2,1,3).contiguous() (minitorch/modules_transfomer.py:67-89): no head-split copies.
-    Returns (out (B, N, H, d) fp32, l (B, H, N), m (B, H, N) or None)."""
+    Returns (out (B, N, H, d) fp32, l (B, H, N), m (B, H, N) or None).
+    ``softmax_scale``: P = softmax(softmax_scale * q.k) instead of the reference's sqrt(1/d) (fa_mi355x_fwd_scaled): for callers that
+    fold the scale into their query projection (modules_transformer.multi_head_attention(fold_scale=True))."""
     if q.dim() != 4:
         raise ValueError("expected (B, N, H, d)")
     for t in (q, k, v):
@@ -171,17 +173,28 @@ def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2):
     out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     l = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
     m = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if variant == _lib.FA_VARIANT_FA1 else None
+    if softmax_scale is not None:
+        _lib.check(_lib.core().fa_mi355x_fwd_scaled(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
+                                                    _lib.FA_LAYOUT_BNHD, float(softmax_scale), int(bool(causal)), variant,
+                                                    _DTYPES[q.dtype], _stream_ptr()))
+        return out, l, m
     _lib.check(_lib.core().fa_mi355x_fwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
                                                 _lib.FA_LAYOUT_BNHD, int(bool(causal)), variant, _DTYPES[q.dtype],
                                                 _stream_ptr()))
     return out, l, m
 
 
-def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2):
-    """Backward on (B, N, H, d) tensors; returns (dq, dk, dv) in the same layout, fp32."""
+def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None):
+    """Backward on (B, N, H, d) tensors; returns (dq, dk, dv) in the same layout, fp32 (``softmax_scale`` as the forward's)."""
     B, N, H, d = q.shape
     ws = _workspace(B * H, N, d, q.device)
     dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
+    if softmax_scale is not None:
+        _lib.check(_lib.core().fa_mi355x_bwd_scaled(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
+                                                    _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d, _lib.FA_LAYOUT_BNHD,
+                                                    float(softmax_scale), int(bool(causal)), variant, _DTYPES[q.dtype],
+                                                    _stream_ptr()))
+        return dq, dk, dv
     _lib.check(_lib.core().fa_mi355x_bwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
                                                 _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d,
                                                 _lib.FA_LAYOUT_BNHD, int(bool(causal)), variant, _DTYPES[q.dtype],

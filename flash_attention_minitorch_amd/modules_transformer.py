@@ -26,18 +26,18 @@ class _FlashAttnBNHD(torch.autograd.Function):
     minitorch/tensor_functions.py:462-497) on (B, N, H, d) tensors."""
 
     @staticmethod
-    def forward(ctx, q, k, v, causal):
-        o, l, _ = device_ops.flash_attn_fwd_bnhd(q, k, v, causal, _lib.FA_VARIANT_FA2)
+    def forward(ctx, q, k, v, causal, softmax_scale=None):
+        o, l, _ = device_ops.flash_attn_fwd_bnhd(q, k, v, causal, _lib.FA_VARIANT_FA2, softmax_scale)
         ctx.save_for_backward(q, k, v, o, l)
-        ctx.causal = causal
+        ctx.causal, ctx.softmax_scale = causal, softmax_scale
         return o
 
     @staticmethod
     def backward(ctx, out_grad):
         q, k, v, o, l = ctx.saved_tensors
         dq, dk, dv = device_ops.flash_attn_bwd_bnhd(q, k, v, o, out_grad.to(q.dtype).contiguous(), l, None, ctx.causal,
-                                                    _lib.FA_VARIANT_FA2)
-        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None
+                                                    _lib.FA_VARIANT_FA2, ctx.softmax_scale)
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None
 
 
 class _FlashAttnBHND(torch.autograd.Function):
@@ -58,14 +58,27 @@ class _FlashAttnBHND(torch.autograd.Function):
         return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None
 
 
-def multi_head_attention(x, wq, wk, wv, wo, n_head: int, causal: bool = True, fused_layout: bool = True):
+LOG2E = 1.4426950408889634
+LN2 = 0.6931471805599453
+
+
+def multi_head_attention(x, wq, wk, wv, wo, n_head: int, causal: bool = True, fused_layout: bool = True, fold_scale: bool = False):
     """MultiHeadAttention.forward (modules_transfomer.py:141-157).  x: (B, N, E); wq, wk, wv, wo: (E, E) (bias-free, as the
     reference's ``Linear(..., bias=False)`` projections, :40-52).  ``fused_layout=False`` reproduces the reference's four
-    permute + contiguous copies (for comparison); both give the same values."""
+    permute + contiguous copies (for comparison); both give the same values.
+    ``fold_scale`` (with ``fused_layout``): log2(e)/sqrt(d) is folded into the query projection's weights and the operator is called
+    with softmax_scale = ln 2 -- the same function of x, but the bf16 MFMA-slot kernels' folded scale is then exactly 1: no extra
+    operand rounding whatever the magnitude of the activations (DESIGN.md section 3 "Scaling")."""
     B, N, E = x.shape
     d = E // n_head
     x2 = x.reshape(B * N, E)
-    if fused_layout:
+    if fused_layout and fold_scale:
+        q = (x2 @ (wq * (LOG2E / d ** 0.5))).view(B, N, n_head, d)
+        k = (x2 @ wk).view(B, N, n_head, d)
+        v = (x2 @ wv).view(B, N, n_head, d)
+        o = _FlashAttnBNHD.apply(q, k, v, causal, LN2)
+        merged = o.reshape(B * N, E)
+    elif fused_layout:
         q = (x2 @ wq).view(B, N, n_head, d)
         k = (x2 @ wk).view(B, N, n_head, d)
         v = (x2 @ wv).view(B, N, n_head, d)
@@ -80,9 +93,9 @@ def multi_head_attention(x, wq, wk, wv, wo, n_head: int, causal: bool = True, fu
     return (merged.to(x.dtype) @ wo).view(B, N, E)
 
 
-def attention_stack(x, layers, n_head: int, causal: bool = True, fused_layout: bool = True):
+def attention_stack(x, layers, n_head: int, causal: bool = True, fused_layout: bool = True, fold_scale: bool = False):
     """x <- x + MultiHeadAttention_l(x) for every (wq, wk, wv, wo) in ``layers``: the attention data flow of the reference's
     4-layer causal DecoderLM (modules_transfomer.py:255-351) without its out-of-scope LayerNorm / FFN blocks."""
     for (wq, wk, wv, wo) in layers:
-        x = x + multi_head_attention(x, wq, wk, wv, wo, n_head, causal, fused_layout)
+        x = x + multi_head_attention(x, wq, wk, wv, wo, n_head, causal, fused_layout, fold_scale)
     return x

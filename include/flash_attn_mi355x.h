@@ -137,6 +137,18 @@ int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* o
                      float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
                      int causal, int variant, int dtype, int stages, const int* opts, int nopts, void* stream);
 
+/* The same two operations with the caller's softmax scale instead of sqrt(1/d): P = softmax_k(softmax_scale * q.k).  The reference's
+ * operator has no such argument (tau = sqrt(1/d) is fixed, src/flash_attn_fw.cu:37); it is here for callers that fold the scale into
+ * their query projection, the usual arrangement in fused-attention stacks: with q' = (log2(e)/sqrt(d)) * q formed in fp32 BEFORE the
+ * rounding to bf16 (i.e. folded into the projection's weights) and softmax_scale = ln(2), the bf16 d = 64 / 128 default kernels' folded
+ * scale tau*log2(e) is exactly 1 and costs no rounding at all (include/flash_attn_mi355x.h "softmax scale").
+ * q_grad is the gradient with respect to the q that was passed in.  Layouts and the other arguments as fa_mi355x_*_layout. */
+int fa_mi355x_fwd_scaled(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H, int N, int d,
+                         int layout, float softmax_scale, int causal, int variant, int dtype, void* stream);
+int fa_mi355x_bwd_scaled(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                         float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int B, int H, int N, int d,
+                         int layout, float softmax_scale, int causal, int variant, int dtype, void* stream);
+
 /* Any head dim d <= 128 on the device path (the reference operator accepts any d up to its assert, src/flash_attn_fw.cu:43; the host
  * launchers above pad on the fly): q, k, v, out_grad, out and the gradients are [batch][N][dp] with dp in {32, 64, 128}, dp >= d, and
  * columns d .. dp-1 of q, k, v, out_grad ZERO (zero columns of q / k add nothing to the scores, zero columns of v / out_grad give zero

@@ -37,7 +37,7 @@ def test_header_declares_expected_entry_points():
     syms = _declared_symbols()
     for s in ("launch_flash_attn_fw", "launch_flash_attn_bw", "fa_mi355x_fwd", "fa_mi355x_bwd",
               "fa_mi355x_bwd_workspace_bytes", "fa_mi355x_launch_fw_host", "fa_mi355x_launch_bw_host",
-              "fa_mi355x_bwd_stages", "fa_mi355x_fwd_layout", "fa_mi355x_bwd_layout", "fa_mi355x_fwd_masked", "fa_mi355x_bwd_masked", "fa_mi355x_fwd_dropout", "fa_mi355x_bwd_dropout", "fa_mi355x_last_error", "fa_mi355x_version", "fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex", "fa_mi355x_bwd_status", "fa_mi355x_measure_mfma_peak", "fa_mi355x_probe", "fa_mi355x_plan", "fa_mi355x_fwd_padded", "fa_mi355x_bwd_padded"):
+              "fa_mi355x_bwd_stages", "fa_mi355x_fwd_layout", "fa_mi355x_bwd_layout", "fa_mi355x_fwd_masked", "fa_mi355x_bwd_masked", "fa_mi355x_fwd_dropout", "fa_mi355x_bwd_dropout", "fa_mi355x_last_error", "fa_mi355x_version", "fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex", "fa_mi355x_bwd_status", "fa_mi355x_measure_mfma_peak", "fa_mi355x_probe", "fa_mi355x_plan", "fa_mi355x_fwd_padded", "fa_mi355x_bwd_padded", "fa_mi355x_fwd_scaled", "fa_mi355x_bwd_scaled"):
         assert s in syms
 
 
