@@ -466,6 +466,35 @@ def test_default_dispatch_around_launch_size_thresholds(dev, BH, N, causal):
         assert maxabs(got[heads], ref[nm]) < TOLBF, (nm, maxabs(got[heads], ref[nm]))
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("opts", [(3,), (4,), (5,), (0, 2), (0, 3), (0, 0, 2), (0, 0, 3), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 1),
+                                  (0, 0, 0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 0, 0, 2)])
+def test_every_accepted_option_value_against_the_oracle(dev, opts, causal):
+    """Every per-call option value the product library accepts (include/flash_attn_mi355x.h; the values that lost their A/B moved
+    to the diagnostic library in round 3), one at a time, bf16 d = 64 at a size where the launch-size rules would otherwise pick for
+    themselves: forward + backward against the fp64 oracle at the ordinary bound."""
+    import torch
+    BH, N, d = 16, 768, 64
+    rng = np.random.default_rng(8800)
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
+    o, l, m = dev.flash_attn_fwd(tq, tk, tv, causal=causal, opts=opts)
+    dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, l, m, causal=causal, opts=opts)
+    heads = [0, 7, 15]
+    ref = oracle_heads(*arrs, causal, heads)
+    for nm, got in (("o", o), ("L", l), ("dq", dq), ("dk", dk), ("dv", dv)):
+        assert maxabs(to_np(got)[heads], ref[nm]) < TOLBF, (opts, nm, maxabs(to_np(got)[heads], ref[nm]))
+
+
+def test_rejected_option_values(dev):
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    q = torch.zeros((2, 256, 64), device="cuda", dtype=torch.bfloat16)
+    for bad in ((1,), (2,), (0, 6), (0, 0, 1), (0, 0, 4), (0, 0, 0, 1), (0, 0, 0, 0, 2), (0, 0, 0, 0, 0, 0, 1), (93,)):
+        with pytest.raises(_lib.FlashAttnLibraryError, match="diagnostic"):
+            dev.flash_attn_fwd(q, q, q, opts=bad)
+
+
 @pytest.mark.parametrize("BH,N", [(24, 512), (5, 768), (40, 256), (16, 2560), (72, 1024)])
 @pytest.mark.parametrize("order", [1, 2])
 def test_causal_slot_builds_block_order(dev, BH, N, order):
