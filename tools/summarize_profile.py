@@ -77,7 +77,8 @@ if pmc:
             traffic[n] = int(rd + wr)
             detail[n] = {"FETCH_SIZE_KB_per_launch": dd["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": dd["WRITE_SIZE"],
                          "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr}
-    if traffic and not tag.endswith("ph") and "causal" not in tag:   # '...ph' (phased-kernel A/B) and causal profiles leave hbm_traffic.json
+    import re
+    if traffic and re.fullmatch(r"r\d+_v\d+", tag):   # only the plain metric-shape profiles (rNN_vM) rewrite hbm_traffic.json   # '...ph' (phased-kernel A/B) and causal profiles leave hbm_traffic.json
         # (which bench.py quotes for the non-causal metric shape) alone
         print("hbm bytes per launch:", traffic)
         traffic["_detail"] = detail
