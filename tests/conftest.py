@@ -27,7 +27,10 @@ def _install_native_backtrace():
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.run(["gcc", "-O1", "-fPIC", "-shared", "-rdynamic", src, "-o", so], check=True, capture_output=True, timeout=60)
         lib = ctypes.CDLL(so)
-        lib.fa_install_abort_trace()
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        log = os.path.join(out_dir if os.path.isdir(out_dir) else tempfile.gettempdir(), "abort_trace.log")
+        lib.fa_install_abort_trace.argtypes = [ctypes.c_char_p]
+        lib.fa_install_abort_trace(log.encode())   # (pytest captures fd 2 per test and drops it when the process dies)
         return lib
     except Exception:   # pragma: no cover
         return None
