@@ -250,7 +250,9 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
 // build (CARE) in a 4-wave geometry that has the registers for it.  A causal launch runs the requested geometry with the
 // sub-slices of queries 0..63 SKIPPED (thin_mode 1) and then one CARE workgroup per batch*head that handles exactly those and
 // adds its dK, dV (thin_mode 2): the main kernel keeps its registers and its speed.
-template <typename T, int D, int KPW, int NW, int QS, int MODE = 0>
+// DROP_ONLY: the instantiation serves dropout calls alone (fp32 d = 64: the plain launches have a build of their own), so the plain
+// kernels of this geometry are not compiled into the library.
+template <typename T, int D, int KPW, int NW, int QS, int MODE = 0, bool DROP_ONLY = false>
 int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, const float* nlc, const float* delta,
                 float* dk, float* dv, int batch, int N, fa::Layout lay, int causal, float tau, hipStream_t st, int care_main = 0,
                 int rank_causal = 1) {
@@ -291,6 +293,9 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
       return FA_OK;
     }
   }
+  if constexpr (DROP_ONLY) {
+    return set_err(FA_ERR_BAD_ARG, "internal: dropout-only dK/dV launch without dropout");
+  } else {
   const int thin = (BF && causal) ? 1 : 0;
   // causal: key blocks p and nkb-1-p share a workgroup (uniform work, no tail: -13 % at the metric shape).  Not for the 8-wave
   // d = 128 geometry, whose register allocation has no room for the pass loop (it would spill).
@@ -312,9 +317,10 @@ int dkdv_launch(const void* q, const void* k, const void* v, const void* dout, c
   if constexpr (BF) {
     if (thin) FA_CARE_LAUNCH(false, batch, 2);
   }
-#undef FA_CARE_LAUNCH
   FA_HIP_TRY(hipGetLastError());
   return FA_OK;
+  }   // !DROP_ONLY
+#undef FA_CARE_LAUNCH
 }
 
 template <typename T, int D, int BN>
@@ -581,9 +587,12 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
                            (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
-      } else   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
+      } else if constexpr (D == 64) {   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal
         // (a build with the masked paths compiled out, for non-causal launches, measured the same: 0.4983 vs 0.4992 ms)
         rc = dkdv_launch<T, D, 32, 8, 128, 3>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st, tun.v[6] == 0 ? 1 : 0);
+      } else {
+        rc = set_err(FA_ERR_BAD_ARG, "internal: no dK/dV kernel selected");   // (d = 32 never gets here: the branch above takes it)
+      }
     } else if constexpr (sizeof(T) == 2) {
 #ifdef FA_DIAG
       if (tun.v[0] == 1)
@@ -592,16 +601,21 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 4, 128>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else
 #endif
-      if (tun.v[0] == 5 || lay.drop_thr)   // two 128-key workgroups per CU (4 waves each); the dropout build needs its registers
+#ifdef FA_DIAG
+      if (tun.v[0] == 5)   // two 128-key workgroups per CU (4 waves each) (A/B: 3.92 vs 3.65 ms)
         rc = dkdv_launch<T, D, 32, 4, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
-      else   // d = 128 default: 8 waves x 32 keys, one 256-key workgroup per CU (half the Q / dO staging per MFMA): 3.64 vs 3.92 ms
+      else
+#endif
+        // d = 128 default (dropout / key mask / N < 64: dkdv_launch runs the 4-wave split-operand build, which has the registers for it): 8 waves x 32 keys, one 256-key workgroup per CU (half the Q / dO staging per MFMA): 3.64 vs 3.92 ms
         rc = dkdv_launch<T, D, 32, 8, 64>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st, 0, tun.v[7] != 1);
     } else if constexpr (D == 64) {
       // fp32, d = 64 (configs[1], [2]): the allocation lands on 256 VGPRs + 2 AGPRs = one wave per SIMD; asking for two
       // (launch bound) keeps it under 256 (tuning key 0 = 1: the unconstrained build)
-      if (tun.v[0] == 1 || lay.drop_thr)
-        rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
+      if (lay.drop_thr)
+        rc = dkdv_launch<T, D, 32, 4, 32, 0, true>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
 #ifdef FA_DIAG
+      else if (tun.v[0] == 1)   // the unconstrained register allocation (A/B)
+        rc = dkdv_launch<T, D, 32, 4, 32>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (tun.v[0] == 5) {   // one 8-wave workgroup per CU instead of two of 4 waves (A/B: 2 % slower)
         const int nkb = (N + 255) / 256;
         FA_LAUNCH((fa::bwd_dkdv_kernel<T, D, 32, 8, 32, 0, false, 2>), dim3(batch * nkb), dim3(512), 0, st,

@@ -110,25 +110,23 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
                          void* stream);
 
 /* Forward / backward with per-call kernel options (no process-wide state): opts[0..nopts-1], nopts <= 8, 0 = default.
- *   opts[0]  dK/dV kernel geometry: 1, 2, 4, 5 = the alternatives measured in profiles/README.md; 3 = the phased kernel with the slot
- *            path on unmasked stages (what causal launches ran before the causal build of the continuous pipeline); 5 at
- *            d = 64, causal, N % 256 == 0: that causal build whatever the launch size
- *   opts[1]  forward kernel: 2 = phased, 3 = slot kernel also under the causal mask (whatever the launch size), 6 = 128-key stages
- *   opts[2]  dQ kernel: 1 / 2 / 4 = phased with 64- / 32-key tiles / 4 waves, 3 = slot kernel also under the causal mask
- *   opts[3]  1 = waves 4-7 of the slot kernels run at s_setprio 1
- *   opts[4]  1 = keep the separate preprocess kernel (default at bf16 d = 64 when the dQ slot kernel runs: the dQ launch preprocesses
- *            its own rows, writes the workspace and runs BEFORE the dK/dV launch; same results up to summation order of delta);
- *            2 = ONE-PASS backward (dQ formed inside the key-stationary kernel and summed across the key-block workgroups of a
- *            head by an ordered hand-off: five products as src/flash_attn2_bw.cu:94-247, no atomics, bitwise reproducible);
- *            bf16, d = 64, non-causal, N a multiple of 256, stages containing both DKDV and DQ; other calls ignore it
+ *   opts[0]  dK/dV kernel: 3 = (d = 64) the phased kernel with the slot path on unmasked stages (what causal launches that do not
+ *            fill the chip run anyway); 4 = the compiler-interleaved phased kernel (fp32 scaling: OPTS_EXACT_SCALE); 5 = at d = 64, causal,
+ *            N % 256 == 0: the causal build of the continuous slot pipeline whatever the launch size
+ *   opts[1]  forward kernel: 2 = phased (fp32 scaling), 3 = slot kernel also under the causal mask (whatever the launch size)
+ *   opts[2]  dQ kernel: 2 = phased with 32-key tiles (fp32 scaling), 3 = slot kernel also under the causal mask
+ *   opts[3]  (diagnostic library only)
+ *   opts[4]  1 = keep the separate preprocess kernel (default: the dQ launch preprocesses its own rows, writes the workspace and runs
+ *            BEFORE the dK/dV launch; same results up to summation order of delta)
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
  *            per workgroup when the launch still covers every CU; bitwise the same results)
- *   opts[6]  1 = causal bf16 d = 64 forward and dK/dV (phased kernels): main kernels + small follow-up launches for the rows with few
- *            keys instead of the single split-operand build (A/B; same results)
+ *   opts[6]  (diagnostic library only)
  *   opts[7]  block order of causal launches: 1 = query blocks p and nqb-1-p paired in one workgroup (slot and phased forward / dQ
  *            kernels) and head-by-head order for the unpaired dK/dV launches (fp32 d = 64, bf16 d = 128); 2 = one block per
  *            workgroup dispatched longest first across a chunk of heads, everywhere; 0 = per kernel what measured faster (slot
  *            builds: ranked below 8 rounds of the chip; phased forward / dQ: paired; unpaired dK/dV: ranked)
+ * Values that lost their A/B in rounds 1-2 (opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1, opts[4] = 2 = the one-pass
+ * backward, opts[6] = 1) exist in the diagnostic library only; the product library answers them with FA_ERR_BAD_ARG.
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
  * library (FA_ERR_BAD_ARG).  `stages` as fa_mi355x_bwd_stages. */
 int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
