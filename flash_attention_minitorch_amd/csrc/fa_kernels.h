@@ -13,7 +13,12 @@
 // (half) rows of the softmax: row max / row sum are register reductions plus one v_permlane32_swap, and the
 // exponentiated tile is directly the B operand of O^T += V^T P^T (no LDS round trip for P).
 //
-// Backward = preprocess (delta = rowsum(dO*O), -L*log2e) + a key-stationary dK/dV kernel (S, dP with the KEY on
+// Scaling (round 3): the MFMA-slot kernels fold tau*log2(e) into their lane-stationary bf16 operand once per block (Q in the forward
+// and dQ kernels, K in the dK/dV kernel), so P = exp2(S') costs one VALU instruction per score; rows with fewer than 64 admissible
+// keys and every phased kernel scale in fp32.  The slot forward sweeps without a softmax reference and redoes a wave's rows in a
+// wave-local cold path when exp2 left its range (fwd_redo_rows).
+//
+// Backward = preprocess (delta = rowsum(dO*O), -L/tau, -L*log2e) + a key-stationary dK/dV kernel (S, dP with the KEY on
 // the lane; P and dS feed dV^T += dO^T P and dK^T += Q^T dS from registers) + a query-stationary dQ kernel
 // (S^T, dP^T with the query on the lane; dQ^T += K^T dS^T).  No atomics: results are bitwise reproducible
 // (the reference's FA-2 backward uses atomicAdd for dQ, src/flash_attn2_bw.cu:228).
