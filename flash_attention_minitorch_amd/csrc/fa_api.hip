@@ -759,15 +759,44 @@ void d2h_rows(float* dst, const float* src, size_t rows, int d, int dp, hipStrea
 // cut into chunks of (batch*head) rows: H2D of chunk c+1, the kernels of chunk c and D2H of chunk c-1 run on three streams
 // (both DMA directions and the compute overlap), and the caller's arrays are pinned in place for the duration of the call
 // (hipHostRegister: no staging copy by the CPU; a range that cannot be pinned is copied pageable, same results).
-struct Pinned {
-  void* p = nullptr;
-  Pinned(const void* ptr, size_t bytes) {
-    if (bytes >= (1u << 20) && hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
-    else (void)hipGetLastError();
+// The caller's arrays, pinned in place for the duration of one host-pointer call.  Round 3: the arrays of a call are registered as
+// PAGE-ALIGNED, MERGED ranges.  Registering each array on its own (round 2) broke intermittently: NumPy arrays of 1-32 MiB come from the
+// malloc heap once glibc has raised its mmap threshold, so two arrays of one call (l and m, say) can share a boundary page; registering
+// overlapping pages twice made a later hipHostUnregister fail ("pointer does not correspond to a registered memory region", which then
+// surfaced as the NEXT call's last error) and, worse, left the runtime with a stale pinned range that a later pageable copy into the
+// recycled pages tripped over (an abort from a runtime thread: seen twice in sixteen runs of the GPU suite).  Unregistering clears the
+// sticky error; every host call starts by clearing whatever an earlier HIP user left behind.
+struct PinSet {
+  struct Range { uintptr_t b, e; };
+  std::vector<Range> want, held;
+  static bool enabled() {   // FA_MI355X_HOST_PIN=0: never pin the caller's arrays (pageable copies: slower, same results)
+    static const bool on = [] { const char* e = getenv("FA_MI355X_HOST_PIN"); return !(e && e[0] == '0'); }();
+    return on;
   }
-  ~Pinned() { if (p) (void)hipHostUnregister(p); }
-  Pinned(const Pinned&) = delete;
-  Pinned& operator=(const Pinned&) = delete;
+  void add(const void* ptr, size_t bytes) {
+    if (!enabled() || !ptr || bytes < (4u << 20)) return;   // (small arrays: the pageable path costs less than a registration)
+    const uintptr_t page = 4096, a = (uintptr_t)ptr;
+    want.push_back(Range{a & ~(page - 1), (a + bytes + page - 1) & ~(page - 1)});
+  }
+  void lock() {
+    std::sort(want.begin(), want.end(), [](const Range& x, const Range& y) { return x.b < y.b; });
+    std::vector<Range> merged;
+    for (const Range& r : want) {
+      if (!merged.empty() && r.b <= merged.back().e) merged.back().e = std::max(merged.back().e, r.e);
+      else merged.push_back(r);
+    }
+    for (const Range& r : merged) {
+      if (hipHostRegister((void*)r.b, r.e - r.b, hipHostRegisterDefault) == hipSuccess) held.push_back(r);
+      else (void)hipGetLastError();   // (already registered by the caller, or not lockable: copied pageable)
+    }
+  }
+  ~PinSet() {
+    for (const Range& r : held)
+      if (hipHostUnregister((void*)r.b) != hipSuccess) (void)hipGetLastError();
+  }
+  PinSet() = default;
+  PinSet(const PinSet&) = delete;
+  PinSet& operator=(const PinSet&) = delete;
 };
 struct HostPipe {
   hipStream_t up = nullptr, down = nullptr;
@@ -1194,7 +1223,11 @@ void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* 
   float* dm_ = (float*)(p + 4 * tb + rb);
   const size_t tbytes = rows * d * sizeof(float), rbytes = rows * sizeof(float);
   HostTimer tm("fw");
-  Pinned pq(q, tbytes), pk(k, tbytes), pv(v, tbytes), po(out, tbytes), pl(l, rbytes), pm(m, variant == FA_VARIANT_FA1 ? rbytes : 0);
+  (void)hipGetLastError();   // (a sticky error of an earlier HIP user is not this call's)
+  PinSet pins;
+  pins.add(q, tbytes); pins.add(k, tbytes); pins.add(v, tbytes); pins.add(out, tbytes); pins.add(l, rbytes);
+  if (variant == FA_VARIANT_FA1) pins.add(m, rbytes);
+  pins.lock();
   tm.pinned();
   const int nch = host_chunks(batch, (size_t)N * d * sizeof(float));
   const int cb = (batch + nch - 1) / nch;
@@ -1252,8 +1285,13 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
   float* ws = (float*)(p + 8 * tb + 2 * rb);   // WS_VECS * rows floats: the row constants of every chunk at its own rows
   const size_t tbytes = rows * d * sizeof(float), rbytes = rows * sizeof(float);
   HostTimer tm("bw");
-  Pinned pq(q, tbytes), pk(k, tbytes), pv(v, tbytes), po(out, tbytes), pdo(out_grad, tbytes), pl(l, rbytes), pm(m, rbytes),
-      pgq(q_grad, tbytes), pgk(k_grad, tbytes), pgv(v_grad, tbytes);
+  (void)hipGetLastError();
+  PinSet pins;
+  for (const float* t : {(const float*)q, (const float*)k, (const float*)v, (const float*)out, (const float*)out_grad,
+                         (const float*)q_grad, (const float*)k_grad, (const float*)v_grad})
+    pins.add(t, tbytes);
+  pins.add(l, rbytes); pins.add(m, rbytes);
+  pins.lock();
   tm.pinned();
   const int nch = host_chunks(batch, (size_t)N * d * sizeof(float));
   const int cb = (batch + nch - 1) / nch;

@@ -51,6 +51,23 @@ OPTS_PHASED = (4, 2, 2)          # the round-1 phased kernels instead of the MFM
 # of larger magnitude (scores of tens) the slot kernels' error grows with 2^-9 * sum_d |tau q_d k_d| and this selection keeps the
 # phased kernels' envelope (tests/test_gpu_parity.py::test_large_magnitude_inputs_stay_finite).
 OPTS_EXACT_SCALE = OPTS_PHASED
+
+
+def pick_opts(q, k, budget=1e-2):
+    """Which kernels for these operands?  Returns None (the default MFMA-slot kernels) when one more 2^-9 rounding of q / k is
+    estimated to move a score by less than ``budget`` (log2 units; root-sum-square estimate with the largest row norms:
+    2^-9 / sqrt(3) * tau*log2(e) * max_row |q| * max_row |k|), else OPTS_EXACT_SCALE (fp32 scaling).  U(-1, 1) inputs give about 6e-3
+    at d = 64 and 7.5e-3 at d = 128: the north star's domain stays on the fast kernels, inputs 1.3x larger and up go to the phased ones
+    (at x2 the slot kernels' error is twice the phased kernels', profiles/r03_prescale_accuracy.txt).  Costs two reductions and ONE
+    host synchronisation: call it once per tensor family (at model set-up, or every few hundred steps), not per attention call.  A model
+    that folds log2(e)/sqrt(d) into its query projection (softmax_scale = ln 2) never needs it."""
+    if q.dtype != torch.bfloat16 or q.shape[-1] not in (64, 128):
+        return None   # fp32 and d = 32 run kernels with fp32 scaling anyway
+    d = q.shape[-1]
+    qn = q.float().norm(dim=-1).amax()
+    kn = k.float().norm(dim=-1).amax()
+    est = float(qn * kn) * (1.4426950408889634 / d ** 0.5) * (2.0 ** -9) / 3.0 ** 0.5
+    return OPTS_EXACT_SCALE if est > budget else None
 OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # DIAGNOSTIC LIBRARY ONLY (tools/check_fused.py): dQ inside the key-stationary kernel, ordered hand-off
 
 

@@ -486,6 +486,27 @@ def test_every_accepted_option_value_against_the_oracle(dev, opts, causal):
         assert maxabs(to_np(got)[heads], ref[nm]) < TOLBF, (opts, nm, maxabs(to_np(got)[heads], ref[nm]))
 
 
+def test_pick_opts_keeps_the_north_star_domain_on_the_fast_kernels(dev):
+    """device_ops.pick_opts: U(-1, 1) operands stay on the default MFMA-slot kernels, operands a few times larger are sent to the kernels
+    with fp32 scaling, and with that choice the x6 inputs of test_large_magnitude_inputs_stay_finite meet the 5e-3 bound."""
+    import torch
+    rng = np.random.default_rng(61)
+    BH, N, d = 4, 512, 64
+    mk = lambda s: torch.from_numpy(oracle.bf16_round(s * rand_u(rng, (BH, N, d)))).to("cuda", torch.bfloat16)
+    assert dev.pick_opts(mk(1.0), mk(1.0)) is None
+    assert dev.pick_opts(mk(1.0).float(), mk(1.0).float()) is None and dev.pick_opts(mk(6.0), mk(6.0)) == dev.OPTS_EXACT_SCALE
+    assert dev.pick_opts(mk(2.0), mk(2.0)) == dev.OPTS_EXACT_SCALE
+    arrs = [oracle.bf16_round(6.0 * rand_u(rng, (BH, N, d))) for _ in range(3)] + [oracle.bf16_round(rand_u(rng, (BH, N, d)))]
+    t = [torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs]
+    opts = dev.pick_opts(t[0], t[1])
+    o, L, _ = dev.flash_attn_fwd(*t[:3], opts=opts)
+    dq, dk, dv = dev.flash_attn_bwd(*t[:3], o, t[3], L, opts=opts)
+    ref = oracle_heads(*arrs, False, range(BH))
+    for nm, got in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
+        scale = max(1.0, float(np.max(np.abs(ref[nm]))))
+        assert maxabs(to_np(got), ref[nm]) < 5e-3 * scale, (nm, maxabs(to_np(got), ref[nm]), scale)
+
+
 def test_rejected_option_values(dev):
     import torch
     from flash_attention_minitorch_amd import _lib
@@ -604,6 +625,50 @@ def test_host_abi_pipeline_multi_chunk(ops, shape, causal):
     o2, l2, _ = ops.flash_attn2_fw(q, q, q, causal)
     ro, rL, _, _ = oracle.dense_attention_fw(f(q)[:1], f(q)[:1], f(q)[:1], causal)
     assert maxabs(f(o2)[:1], ro) < TOL32 and maxabs(l2.reshape(B * H, N)[:1], rL) < TOL32
+
+
+def test_host_abi_arrays_that_share_pages(golden_dir):
+    """The host launchers pin the caller's arrays in place (hipHostRegister).  NumPy arrays of a few MiB come from the malloc heap once
+    glibc has raised its mmap threshold, so the arrays of ONE call can be adjacent and share boundary pages.  Round 2 registered every
+    array on its own: overlapping registrations then made a later hipHostUnregister fail (surfacing as the NEXT call's
+    "pointer does not correspond to a registered memory region" + exit) or left the runtime with a stale pinned range (an abort in a
+    later, unrelated copy): about one GPU-suite run in six.  Round 3 registers page-aligned MERGED ranges.  Here every array of a
+    forward and a backward call is carved, unaligned and back to back, out of ONE buffer (l and m >= 1 MiB so that they are pinned
+    too), through the reference's own FFI symbols, twice, then an ordinary call follows."""
+    import ctypes
+    from flash_attention_minitorch_amd import _lib
+    from flash_attention_minitorch_amd.cuda_kernel_ops import _FW_ARGTYPES, _BW_ARGTYPES, CudaKernelOps
+    BH, N, d = 128, 2048, 32
+    nt, nr = BH * N * d, BH * N
+    sizes = [nt] * 8 + [nr] * 2                       # q k v out dout dq dk dv | l m
+    buf = np.zeros(sum(sizes) + 64 * len(sizes) + 1024, np.float32)
+    views, off = [], 3                                # 12 bytes off the buffer's alignment, 4-byte gaps' worth of odd spacing
+    for i, n in enumerate(sizes):
+        views.append(buf[off:off + n])
+        off += n + 1 + 2 * i                          # adjacent: consecutive arrays share their boundary page
+    q, k, v, out, dout, dq, dk, dv, l, m = views
+    rng = np.random.default_rng(515)
+    for a in (q, k, v, dout):
+        a[:] = rand_u(rng, a.shape)
+    fw, bw = _lib.load("flash_attn2_fw.so"), _lib.load("flash_attn2_bw.so")
+    fw.launch_flash_attn_fw.argtypes, bw.launch_flash_attn_bw.argtypes = _FW_ARGTYPES, _BW_ARGTYPES
+    fw.launch_flash_attn_fw.restype = bw.launch_flash_attn_bw.restype = None
+    null = ctypes.c_void_p(0)
+    for _ in range(2):
+        m[:] = -FLT_MAX
+        fw.launch_flash_attn_fw(q, k, v, out, l, m, BH, N, d, False, null)
+        bw.launch_flash_attn_bw(q, k, v, out, dout, dq, dk, dv, l, m, BH, N, d, False, null)
+    f = lambda a: a.reshape(BH, N, -1)
+    heads = [0, 77, 127]
+    ref = oracle_heads(f(q), f(k), f(v), f(dout), False, heads)
+    assert maxabs(f(out)[heads], ref["o"]) < TOL32 and maxabs(l.reshape(BH, N)[heads], ref["L"]) < TOL32
+    for nm, g in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert maxabs(f(g)[heads], ref[nm]) < TOL32, nm
+    # ... and the next, ordinary call (fresh arrays) and a device-path round trip are unaffected
+    q4 = rand_u(rng, (2, 2, 256, 64))
+    o4, l4, _ = CudaKernelOps.flash_attn2_fw(q4, q4, q4, True)
+    ro, rL, _, _ = oracle.dense_attention_fw(q4, q4, q4, True)
+    assert maxabs(o4, ro) < TOL32 and maxabs(l4, rL) < TOL32
 
 
 # ---------------------------------------------------------------- row f3: flash vs vanilla attention ON THE GPU
