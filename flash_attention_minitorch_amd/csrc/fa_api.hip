@@ -773,8 +773,10 @@ struct PinSet {
     static const bool on = [] { const char* e = getenv("FA_MI355X_HOST_PIN"); return !(e && e[0] == '0'); }();
     return on;
   }
+  // EVERY host array of the call is added, whatever its size: an array that shares a page with a pinned neighbour must lie inside the
+  // pinned range as a whole (a copy that starts inside a registered range and runs past its end is an invalid argument to HIP)
   void add(const void* ptr, size_t bytes) {
-    if (!enabled() || !ptr || bytes < (4u << 20)) return;   // (small arrays: the pageable path costs less than a registration)
+    if (!enabled() || !ptr || !bytes) return;
     const uintptr_t page = 4096, a = (uintptr_t)ptr;
     want.push_back(Range{a & ~(page - 1), (a + bytes + page - 1) & ~(page - 1)});
   }
@@ -786,6 +788,7 @@ struct PinSet {
       else merged.push_back(r);
     }
     for (const Range& r : merged) {
+      if (r.e - r.b < (4u << 20)) continue;   // (small and on pages of its own: the pageable path costs less than a registration)
       if (hipHostRegister((void*)r.b, r.e - r.b, hipHostRegisterDefault) == hipSuccess) held.push_back(r);
       else (void)hipGetLastError();   // (already registered by the caller, or not lockable: copied pageable)
     }
@@ -1225,8 +1228,7 @@ void fa_mi355x_launch_fw_host(int variant, float* q, float* k, float* v, float* 
   HostTimer tm("fw");
   (void)hipGetLastError();   // (a sticky error of an earlier HIP user is not this call's)
   PinSet pins;
-  pins.add(q, tbytes); pins.add(k, tbytes); pins.add(v, tbytes); pins.add(out, tbytes); pins.add(l, rbytes);
-  if (variant == FA_VARIANT_FA1) pins.add(m, rbytes);
+  pins.add(q, tbytes); pins.add(k, tbytes); pins.add(v, tbytes); pins.add(out, tbytes); pins.add(l, rbytes); pins.add(m, rbytes);
   pins.lock();
   tm.pinned();
   const int nch = host_chunks(batch, (size_t)N * d * sizeof(float));
