@@ -122,3 +122,34 @@ def sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_loca
     if not gather:
         return dq, dk, dv
     return tuple(all_gather_bh(g, bh_total, group) for g in (dq, dk, dv))
+
+
+def sharded_flash_attn2_bwd_overlapped(q_local, k_local, v_local, o_local, do_local, L_local, bh_total: int,
+                                       causal: bool = False, chunks: int = 4, group=None,
+                                       compute_fn: Optional[Callable] = None):
+    """sharded_flash_attn2_bwd(..., gather=True) with the three gradient gathers hidden under the compute, as
+    sharded_flash_attn2_fwd_overlapped does for O: the local slice is cut into ``chunks`` pieces along batch*head, the gathers of piece
+    c (dQ, dK, dV: all-gathers, never a reduction -- gradients of different (b, h) do not overlap) run while piece c+1 computes, and
+    every piece lands at its final rows.  Needs an even split; otherwise it falls back to the one-shot gathers."""
+    fn = compute_fn or _default_bwd
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(bh_total, world)
+    bh_local = q_local.shape[0]
+    if len({e - b for b, e in bounds}) != 1 or chunks <= 1 or bh_local % chunks != 0:
+        return sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_local, bh_total, causal, True, group,
+                                       compute_fn)
+    cs = bh_local // chunks
+    full = None
+    pending, keep = [], []
+    for c in range(chunks):
+        sl = slice(c * cs, (c + 1) * cs)
+        grads = tuple(g.contiguous() for g in fn(q_local[sl], k_local[sl], v_local[sl], o_local[sl], do_local[sl], L_local[sl], causal))
+        if full is None:
+            full = tuple(torch.empty((bh_total,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device) for g in grads)
+        rows = [slice(b + c * cs, b + (c + 1) * cs) for b, _ in bounds]
+        for dst, g in zip(full, grads):
+            pending.append(dist.all_gather([dst[r] for r in rows], g, group=group, async_op=True))
+        keep.append(grads)   # the pieces must outlive their collectives
+    for work in pending:
+        work.wait()
+    return full

@@ -48,8 +48,10 @@ def test_sharded_default_compute_small_slice_against_oracle(group):
     o2, L2 = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH, chunks=2)
     o_loc, L_loc = sharded.sharded_flash_attn2_fwd(q, k, v, BH, gather=False)
     dq, dk, dv = sharded.sharded_flash_attn2_bwd(q, k, v, o_loc, do, L_loc, BH)
+    g2 = sharded.sharded_flash_attn2_bwd_overlapped(q, k, v, o_loc, do, L_loc, BH, chunks=2)
     torch.cuda.synchronize()
     assert torch.equal(o, o2) and torch.equal(L, L2) and torch.equal(o, o_loc)
+    assert all(torch.equal(a, b) for a, b in zip((dq, dk, dv), g2))
     heads = [0, 3]
     arrs = [to_np(t.float())[heads] for t in (q, k, v, do)]
     ref = oracle_heads(*arrs, False, range(len(heads)))

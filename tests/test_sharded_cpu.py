@@ -48,6 +48,9 @@ def _worker(rank, world, port, bh_total, causal, out_dir, N=24, d=16, chunks=Non
         o2, L2 = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, bh_total, causal,
                                                             chunks=chunks or (3 if (e - b) % 3 == 0 else 2), compute_fn=_oracle_fwd)
         assert torch.equal(o2, o) and torch.equal(L2, L)
+        g2 = sharded.sharded_flash_attn2_bwd_overlapped(q, k, v, o_loc, do, L_loc, bh_total, causal,
+                                                        chunks=chunks or (3 if (e - b) % 3 == 0 else 2), compute_fn=_oracle_bwd)
+        assert all(torch.equal(a, b_) for a, b_ in zip(g2, (dq, dk, dv)))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), o=o.numpy(), L=L.numpy(), dq=dq.numpy(), dk=dk.numpy(),
                  dv=dv.numpy())
     finally:
