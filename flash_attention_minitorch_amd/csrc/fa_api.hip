@@ -188,14 +188,14 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
     if (variant == FA_VARIANT_FA2 && tun.v[1] != 2 && (!causal || tun.v[1] == 3 || cslot) && !lay.kmask && !lay.drop_thr && N >= 64) {
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
-      if (whole && tun.v[1] == 94 && D == 64) {   // timing ablation: no per-stage barrier (WRONG results)
-        FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 2, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+      if (whole && tun.v[1] == 94) {   // timing ablation: no per-stage barrier (WRONG results)
+        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false, 2, 64, (D == 64 ? 4 : 2)>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
-      if (whole && tun.v[1] == 93 && D == 64) {   // phase stamps (never timed)
-        FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 1, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+      if (whole && tun.v[1] == 93) {   // phase stamps (never timed)
+        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false, 1, 64, (D == 64 ? 4 : 2)>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;

@@ -8,7 +8,7 @@ import numpy as np, torch
 import os as _os
 _os.environ["FA_MI355X_DIAG"] = "1"   # tools use the diagnostic build (set_tuning, stamps, ablations)
 from flash_attention_minitorch_amd import device_ops, _lib
-B, H, N, d = 8, 8, 4096, 64
+B, H, N, d = map(int, os.environ.get("FA_SHAPE", "8,8,4096,64").split(","))   # FA_SHAPE=16,16,4096,128: configs[3]'s shape (forward stamps only)
 BH = B * H
 mk = lambda: ((torch.rand((BH, N, d), device="cuda") - 0.5) * 2).to(torch.bfloat16)
 q, k, v, do = mk(), mk(), mk(), mk()
