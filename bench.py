@@ -348,15 +348,14 @@ def main():
     # shows them (fa::<name><...>).
     STAGES, K_FWD, K_DQ, K_DKDV = stage_plan(device_ops, BH, N, d, causal, args.dtype, OPTS, fwd, bwd)
     breakdown = not args.no_kernel_breakdown
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)] \
-        if breakdown else None
 
-    def step(ev=None):
-        if ev is not None:
+    def step(ev=None, only=-1):
+        # ev: one HIP event per kernel boundary (len(STAGES) + 1 of them); only >= 0: record just the two around stage `only`
+        if ev is not None and only <= 0:
             ev[0].record()
         for i, (_, fn) in enumerate(STAGES):
             fn()
-            if ev is not None:
+            if ev is not None and (only < 0 or i + 1 == only or i == only):
                 ev[i + 1].record()
 
     def barrier():
@@ -375,6 +374,20 @@ def main():
         settle_ms = (time.perf_counter() - ts) * 1e3
         if settle_ms >= SETTLE_MS:
             break
+    # Every kernel's launch duration, by HIP events between the launches, over --steps untimed steps of the settled load: the
+    # `kernels_ms` key, and which kernel is the dominant one.  An event between two kernels costs the step about 3 us, so the timed
+    # region below keeps only the two events around the dominant kernel (roofline.avg_launch_ms is measured THERE, live).
+    new_events = lambda: [[torch.cuda.Event(enable_timing=True) for _ in range(len(STAGES) + 1)] for _ in range(args.steps)]
+    pre_events = None
+    dom_stage = -1
+    if breakdown:
+        pre_events = new_events()
+        for i in range(args.steps):
+            step(pre_events[i])
+        torch.cuda.synchronize()
+        per_stage = [sum(ev[i].elapsed_time(ev[i + 1]) for ev in pre_events) / args.steps for i in range(len(STAGES))]
+        dom_stage = max(range(len(STAGES)), key=lambda i: per_stage[i])
+    events = new_events() if breakdown else None
     for _ in range(args.warmup):
         step()
 
@@ -382,7 +395,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(ev_rows[i] if ev_rows is not None else None)
+            step(ev_rows[i] if ev_rows is not None else None, dom_stage)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -411,10 +424,11 @@ def main():
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
         alg = {K_FWD: flops_fw, "bwd_prep_kernel": 0.0, K_DKDV: 8.0 * BH * N * N * d * cf,
                K_DQ: 2.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw}
-        for i, (name, _) in enumerate(STAGES):
-            ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / args.steps
+        for i, (name, _) in enumerate(STAGES):   # the dominant kernel: from the timed region; the others: the pass before it
+            evs = events if i == dom_stage else pre_events
+            ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in evs) / args.steps
             kernels[name] = (ms, alg[name])
-        dom = max(kernels, key=lambda n: kernels[n][0])
+        dom = STAGES[dom_stage][0]
         dur_ms, fl = kernels[dom]
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = fl / (dur_ms * 1e-3) / 1e12
@@ -523,6 +537,8 @@ def main():
             "sustained_mfma_peak": sustained,
             "cpu_baseline": cpu_baseline,
             "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
+            "kernels_ms_source": "HIP events: roofline.kernel inside the timed region (two events per step); the others over the "
+                                 "same number of untimed steps just before the warm-up (an event per kernel boundary)",
             "settle_ms": round(settle_ms, 1),
             "ms_per_step_blocks": blocks_ms,
             "ms_per_step_median": med_ms,
