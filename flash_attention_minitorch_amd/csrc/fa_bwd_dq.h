@@ -281,9 +281,9 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // their register pressure at the joins disappear.
 // CDIAG = true (MASKS = false, N a multiple of 256): the causal launch, as fwd_slot_kernel's: the pipeline sweeps the 2 * qb full
 // stages in front of the workgroup's first query without a mask; the 256 keys of its own diagonal block are the next two stages of
-// the ring (requested by the last iteration) and are taken wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles
-// 0..w and masks the last one; rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p
-// share a workgroup (uniform work).
+// the ring.  Waves 4-7 sweep the first of them too (it lies wholly in front of their first query; round 3); what is left is taken
+// wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles 0..w (waves 0-3) or 4..w (waves 4-7) and masks the last one;
+// rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p share a workgroup (uniform work).
 template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
@@ -386,7 +386,12 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     for (int off = tid * 16; off < 6 * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
   }
-  if (!CDIAG || nstage > 0) {   // (causal build: query block 0 has no key in front of its diagonal block)
+  // Causal build: waves 4-7 keep sweeping through the first stage of the workgroup's own diagonal block (its 128 keys lie wholly in
+  // front of their first query); every wave takes part in all stage hand-offs (DMA share, wait, barrier), waves 0-3 without periods
+  // in the last one.
+  const int nst_w = CDIAG ? nstage + (w >> 2) : nstage;   // stages this wave sweeps (wave-uniform)
+  const int nst_all = CDIAG ? nstage + 1 : nstage;        // stage hand-offs every wave takes part in
+  {
   stage_dma(0, 0);
   dma_wait_all();   // this wave's pieces have landed
   __syncthreads();
@@ -515,11 +520,11 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   dsB1 = A::zero();
   SB();
   period(T1, T0, T0, T0, ic<0>{}, ic<0>{}, ic<1>{}, cr0, cr1, ct0, ct1, cr0, cr1, 0, sA, dpA, sB, dpB, dsB0, dsB1, dsA0, dsA1);
-  for (int st = 0; st < nstage; ++st) {
+  for (int st = 0; st < nst_w; ++st) {
     const bool more = st + 1 < nstage;
     const int nb = slot_of(st + 1);
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;   // rows of the next stage
-    if (CDIAG || more) stage_dma((st + 1) * ST, nb);   // (causal build: the diagonal block follows the sweep)
+    if (CDIAG || more) stage_dma((st + 1) * ST, nb);   // (causal build: the two stages of the diagonal block follow the sweep)
     const int kb = st * ST;
     // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
     auto need = [&](int sub) { return MASKS && ((kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0)); };
@@ -543,7 +548,6 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     if constexpr (DIAG == 1) { t0 = stamp(); ph[2] += t0 - t1; }
     if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
     if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
-    if (CDIAG && !more) stage_dma((st + 2) * ST, slot_of(st + 2));   // second diagonal stage: its slot was last read one period ago
     // period 4st+2: produce sub 3, consume sub 2, dQ of sub 1; rows two ahead = sub 0 of the next stage
     if constexpr (MASKS) {
       if (need(2)) period(T1, T1, T1, T1, ic<3>{}, ic<1>{}, ic<0>{}, cr0, cr1, ct0, ct1, nr0, nr1, kb + 64, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
@@ -564,19 +568,22 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   }
   // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
   period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+  if constexpr (CDIAG) {   // the stage hand-off this wave has no periods for (same DMA share, wait and barrier as in the loop)
+    for (int st = nst_w; st < nst_all; ++st) {
+      stage_dma((st + 1) * ST, slot_of(st + 1));
+      dma_wait_all();
+      __syncthreads();
+    }
+  }
   }
 
   if constexpr (CDIAG) {
-    // The diagonal block: keys kmax .. kmax + 255 = stages nstage, nstage + 1 of the ring (slots nstage % 3, (nstage + 1) % 3).
-    if (nstage == 0) {
-      stage_dma(0, 0);
-      stage_dma(ST, TB);
-    }
-    dma_wait_all();
-    __syncthreads();
+    // The diagonal block: keys kmax .. kmax + 255 = stages nstage, nstage + 1 of the ring (slots nstage % 3, (nstage + 1) % 3), both
+    // requested and published by the hand-offs above.  Left for the plain per-sub-tile form: sub-tiles 0..w (waves 0-3), 4..w
+    // (waves 4-7, which swept the block's first stage): at most four per wave instead of up to eight.
     const bool careful = exactq;   // wave-uniform
     const float cmd = exactq ? c : 1.0f;   // (the other waves' scores leave the MFMA chain in log2 units)
-    for (int j = 0; j <= w; ++j) {
+    for (int j = 4 * (w >> 2); j <= w; ++j) {
       const int sb = ((nstage + (j >> 2)) % 3) * TB;
       lds_char* tk = smem + sb;
       lds_char* tv = tk + VOFF;

@@ -16,6 +16,15 @@ template <int V> using ic = std::integral_constant<int, V>;
 // Diagnostic builds only (MODE == 9 instantiation of the dK/dV kernel): per-wave cycle totals per loop phase,
 // written to a buffer of their own that no other code reads.  The real kernels execute no stamp.
 __device__ unsigned long long g_phase_cycles[8 * 8192];
+// The lane id, recomputed on the spot (two VALU instructions the compiler can neither hoist nor keep alive across a loop): lane
+// constants that are only needed in front of and behind a register-starved pipeline are re-derived instead of being carried (and
+// spilled) through it (cdna_hip_programming.md, Appendix B: 'recompute per block (v_mbcnt)').
+FA_DEV int lane_fresh() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 FA_DEV unsigned long long stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);

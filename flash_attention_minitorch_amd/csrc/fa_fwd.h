@@ -376,9 +376,11 @@ FA_DEV void fwd_redo_rows(rsrc_t qrs, rsrc_t krs, rsrc_t vrs, int qrow, int q0, 
 // CDIAG = true (MASKS = false, 64-key stages, N a multiple of 256): the causal launch.  The pipeline above sweeps the keys in
 // front of the workgroup's first query (4 * qb full stages, no sub-tile of them needs a mask, so the unmasked build keeps its
 // registers and its four waves per SIMD); the 256 keys of the workgroup's own diagonal block are the NEXT four stages of the same
-// ring (prefetched by the last iterations) and are then taken wave by wave the classic way (true maximum, reference moved):
-// wave w multiplies sub-tiles 0..w of the block and masks the last one.  Rows 0..63 (fewer than 64 admissible keys) split P
-// into two bf16 fragments there (Atom::pack_lo), which is what the phased CARE build does for them.
+// ring.  Wave w keeps sweeping through the first w / 2 of them (they lie wholly in front of its first query; every wave takes part
+// in all stage hand-offs, without periods once its own sweep has ended) and takes what is left, sub-tiles 2 * (w / 2) .. w of the
+// block, the classic way (true maximum, reference moved), masking the last one: at most two plain sub-tiles per wave instead of up
+// to eight (round 3).  Rows 0..63 (fewer than 64 admissible keys) split P into two bf16 fragments there (Atom::pack_lo), which is
+// what the phased CARE build does for them.
 template <typename T, int D, bool MASKS = true, int DIAG = 0, int STK = 8192 / D, int MINW = 2, bool CDIAG = false>
 __global__ void __launch_bounds__(512, MINW)
 fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
@@ -406,7 +408,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   __shared__ __attribute__((aligned(16))) char smem_raw[2 * R * TB];
   lds_char* smem = (lds_char*)smem_raw;
 
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r0_ = lane & 31, h0_ = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // The causal build pairs query block p with block nqb-1-p in one workgroup (heavy one first): every workgroup sweeps the same
   // number of stages (the launcher sizes the grid with (nqb + 1) / 2 blocks per batch*head).
@@ -425,8 +427,16 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   for (int pass = 0; pass < npass; ++pass) {
   const int qb = CDIAG ? (pass == 0 ? nqb - 1 - pblk : pblk) : (causal ? nqb - 1 - pblk : pblk);
   if (CDIAG && pass) __syncthreads();   // every wave is done with the diagonal image of the first block
-  const int q0 = qb * 256 + w * 32, qrow = q0 + r;
-  const bool qvalid = qrow < N;
+  // (causal build: the lane's row constants are re-derived where they are needed -- here, behind the sweep, in the epilogue -- so
+  // that the pipeline, which sits at its 128 registers, does not carry them)
+  int r = r0_, h = h0_;
+  if constexpr (CDIAG) {
+    const int l2 = lane_fresh();
+    r = l2 & 31;
+    h = l2 >> 5;
+  }
+  const int q0 = qb * 256 + w * 32;
+  int qrow = q0 + r;
 
   frag qf[KC];
 #pragma unroll
@@ -476,9 +486,14 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     for (int off = tid * 16; off < 2 * R * TB; off += 512 * 16) *FA_LDS(u32x4, smem + off) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
   }
-  if (!CDIAG || nstage > 0) {   // (causal build: query block 0 has no key in front of its diagonal block)
+  // Causal build: the sweep also takes, wave by wave, the stages of the workgroup's own diagonal block that lie wholly in front of
+  // the wave's first query (wave w: the first w / 2 of the block's four 64-key stages); every wave runs the same number of stage
+  // hand-offs (DMA share, wait, barrier), the ones past its own sweep without the periods.
+  const int nst_w = CDIAG ? nstage + (w >> 1) : nstage;   // stages this wave sweeps (wave-uniform)
+  const int nst_all = CDIAG ? nstage + 3 : nstage;        // stage hand-offs every wave takes part in
+  {
   stage_dma(0, 0);
-  if (NSUBT == 2 && nstage > 1) stage_dma(ST, slot_of(1));
+  if (NSUBT == 2 && (CDIAG || nstage > 1)) stage_dma(ST, slot_of(1));
   dma_wait_all();
   __syncthreads();
   if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
@@ -628,7 +643,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     m_ref = tile_max(sA);      // key 0 is never masked, so the maximum is finite
     nmc = -m_ref * c;
   }
-  for (int st = 0; st < nstage; ++st) {
+  for (int st = 0; st < nst_w; ++st) {
     const int nb = slot_of(st + 1);
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;
     const int kb = st * ST;
@@ -678,7 +693,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         if constexpr (DIAG != 2) __syncthreads();   // DIAG 2: timing ablation without the per-stage barrier (results are wrong)
         if constexpr (DIAG == 1) { t1 = stamp(); ph[3] += t1 - t0; t0 = t1; }
       }
-      if (CDIAG || st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));   // (causal build: the diagonal block follows)
+      if (CDIAG ? st + 2 < nstage + 4 : st + 2 < nstage) stage_dma((st + 2) * ST, slot_of(st + 2));   // (causal build: the diagonal block's four stages follow)
       // period 2st+0: produce sub 1, softmax of sub 0, P.V of sub 1 of the previous stage; rows two ahead: next stage, sub 0
       if constexpr (MASKS) {
         if (need(0)) period(T1, T1, T1, T1, ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, nr0, nr1, cr0, cr1, kb, sB, sA, pB0, pB1, pA0, pA1);
@@ -700,19 +715,28 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   }
   // drain: P.V of the last sub-tile (the buffers alternate per sub-tile: an even count per stage ends on B)
   period(T0, T0, T1, T0, ic<0>{}, ic<NSUBT - 1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
+  if constexpr (CDIAG) {   // the stage hand-offs this wave has no periods for (same DMA share, wait and barrier as in the loop)
+    for (int st = nst_w; st < nst_all; ++st) {
+      if (st > 0) {
+        dma_wait_all();
+        __syncthreads();
+      }
+      if (st + 2 < nstage + 4) stage_dma((st + 2) * ST, slot_of(st + 2));
+    }
+  }
   }
 
   if constexpr (CDIAG) {
     // The diagonal block: keys kmax .. kmax + 255 = stages nstage .. nstage + 3 of the ring = slots 0 .. 3 (nstage % 4 == 0), i.e.
-    // ONE 256-row image of K at smem and of V at smem + VOFF.  Stages nstage, nstage + 1 were requested by the sweep.
-    if (nstage == 0) {
-      stage_dma(0, 0);
-      stage_dma(ST, TB);
+    // ONE 256-row image of K at smem and of V at smem + VOFF, all of it requested by the sweep's hand-offs.  What is left for the
+    // classic per-sub-tile form: the sub-tiles from the wave's last swept stage up to its own (one or two of them).  (The last
+    // hand-off above published the block's last stage: no further wait.)
+    {
+      const int l2 = lane_fresh();
+      r = l2 & 31;
+      h = l2 >> 5;
+      qrow = q0 + r;
     }
-    dma_wait_all();
-    __syncthreads();   // slots 0, 1 published; every wave is past its last read of slots 2, 3
-    stage_dma(kmax + 2 * ST, 2 * TB);
-    stage_dma(kmax + 3 * ST, 3 * TB);
     const bool careful = exactq;   // wave-uniform
     auto diag_tile = [&](int j, bool first) {
       f32x16 s;
@@ -772,11 +796,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
           }
       }
     };
-    const int jmid = min(w, 3);
-    for (int j = 0; j <= jmid; ++j) diag_tile(j, nstage == 0 && j == 0);
-    dma_wait_all();
-    __syncthreads();   // slots 2, 3 published
-    for (int j = 4; j <= w; ++j) diag_tile(j, false);
+    for (int j = 2 * (w >> 1); j <= w; ++j) diag_tile(j, nst_w == 0 && j == 0);
   }
 
   if constexpr (DIAG == 1) { t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
@@ -784,6 +804,12 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   if constexpr (PRE) {   // a row sum outside [2^-96, 2^96] (or NaN): exp2(S') over- or underflowed somewhere in the wave's rows
     if (__any(!(l_tot >= 0x1p-96f && l_tot <= 0x1p96f))) {
       const uint32_t kv_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
+      if constexpr (CDIAG) {
+        const int l2 = lane_fresh();
+        r = l2 & 31;
+        h = l2 >> 5;
+        qrow = q0 + r;
+      }
       fwd_redo_rows<D>(qrs, make_rsrc(k + base, kv_bytes), make_rsrc(v + base, kv_bytes), qrow, q0, ld, N, CDIAG, c, r, h, acc_o,
                        m_ref, l_run);
       l_tot = xhalf_sum(l_run);
@@ -793,7 +819,13 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   // (the output addresses are formed HERE from opaque copies: computed before the loop, hipcc keeps the 64-bit row pointers live
   // through the pipeline, and the causal d = 64 build, which sits at its 128 registers, spills them around the loop)
   int qr = qrow, hh = h;
-  asm volatile("" : "+v"(qr), "+v"(hh));
+  if constexpr (CDIAG) {
+    const int l2 = lane_fresh();
+    qr = q0 + (l2 & 31);
+    hh = l2 >> 5;
+  } else {
+    asm volatile("" : "+v"(qr), "+v"(hh));
+  }
   if (qr < N) {
     float* orow = o + base + (size_t)qr * ld;
 #pragma unroll
