@@ -284,7 +284,11 @@ bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restr
 // the ring.  Waves 4-7 sweep the first of them too (it lies wholly in front of their first query; round 3); what is left is taken
 // wave by wave in plain per-sub-tile form: wave w multiplies sub-tiles 0..w (waves 0-3) or 4..w (waves 4-7) and masks the last one;
 // rows 0..63 split dS into two bf16 fragments there (Atom::pack_lo).  Query blocks p and nqb-1-p share a workgroup (uniform work).
-template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false>
+// TILED = true (MASKS = false, non-causal; round 3): a workgroup takes lay.tiles CONSECUTIVE query blocks of one head, one after the
+// other, without leaving the pipeline's ring: the last stage iteration of a block requests key stage 0 again into the next ring slot
+// (the ring simply goes on: stage j of the next block is ring stage nstage + j), so the next block starts at its prologue period with
+// no DMA wait and no barrier, and its Q / dO / O loads run while the dQ stores of the finished block drain.
+template <typename T, int D, int DIAG = 0, bool MASKS = true, bool CDIAG = false, bool TILED = false>
 __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                    const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
@@ -301,8 +305,10 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   static_assert(!CDIAG || (!MASKS && DIAG == 0), "causal build: unmasked sweep + diagonal block");
+  static_assert(!TILED || (!MASKS && !CDIAG && DIAG == 0), "tiled build: non-causal, unmasked, no stamps");
+  const int tiles = TILED ? max(lay.tiles, 1) : 1;   // query blocks per workgroup (the launcher sizes the grid with nqb / tiles per head)
   const bool ranked = CDIAG && causal == 2;   // A/B: one block per workgroup, heaviest blocks of all heads first
-  const int nblk = (CDIAG && !ranked) ? (nqb + 1) / 2 : nqb;
+  const int nblk = TILED ? nqb / tiles : ((CDIAG && !ranked) ? (nqb + 1) / 2 : nqb);
   int bh, pblk;
   if (ranked) map_block_ranked(blockIdx.x, BH, nblk, max(lay.rank_chunk, 1), bh, pblk);
   else map_block(blockIdx.x, BH, nblk, bh, pblk);
@@ -312,9 +318,10 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   const rsrc_t qrs = make_rsrc(q + base, mat_bytes);
   const rsrc_t dors = make_rsrc(dout + base, mat_bytes);
   const float c = tau * LOG2E;
-  const int npass = (CDIAG && !ranked && pblk != nqb - 1 - pblk) ? 2 : 1;
+  const int npass = TILED ? tiles : ((CDIAG && !ranked && pblk != nqb - 1 - pblk) ? 2 : 1);
+  int roff = 0;   // tiled build: ring position of the current block's stage 0
   for (int pass = 0; pass < npass; ++pass) {
-  const int qb = CDIAG ? (pass == 0 ? nqb - 1 - pblk : pblk) : (causal ? nqb - 1 - pblk : pblk);
+  const int qb = TILED ? pblk * tiles + pass : (CDIAG ? (pass == 0 ? nqb - 1 - pblk : pblk) : (causal ? nqb - 1 - pblk : pblk));
   if (CDIAG && pass) __syncthreads();   // every wave is done with the diagonal stages of the first block
   const int q0 = qb * 256 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
@@ -392,9 +399,11 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   const int nst_w = CDIAG ? nstage + (w >> 2) : nstage;   // stages this wave sweeps (wave-uniform)
   const int nst_all = CDIAG ? nstage + 1 : nstage;        // stage hand-offs every wave takes part in
   {
-  stage_dma(0, 0);
-  dma_wait_all();   // this wave's pieces have landed
-  __syncthreads();
+  if (!(TILED && pass > 0)) {   // (tiled build: the last iteration of the block before requested and published this stage)
+    stage_dma(0, 0);
+    dma_wait_all();   // this wave's pieces have landed
+    __syncthreads();
+  }
   if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
   if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
@@ -509,9 +518,10 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   auto T1 = ic<1>{};
   auto T0 = ic<0>{};
   // per-stage address registers: K slot of stage s is s % 3
-  auto slot_of = [&](int st) { return (st % 3) * TB; };
-  int cr0 = ra.b[0], cr1 = ra.b[1];                 // rows of the current stage (slot 0)
-  int ct0 = ta.b[0], ct1 = ta.b[1];                 // transposed reads of the current stage
+  auto slot_of = [&](int st) { return ((st + roff) % 3) * TB; };
+  const int b0_ = slot_of(0);
+  int cr0 = ra.b[0] + b0_, cr1 = ra.b[1] + b0_;     // rows of the current stage (slot 0; tiled build: where the ring stands)
+  int ct0 = ta.b[0] + b0_, ct1 = ta.b[1] + b0_;     // transposed reads of the current stage
   int pt0 = ct0, pt1 = ct1;                         // ... of the previous stage (stage 0: any finite data, dS = 0)
   // prologue: rows of sub-tile 0, then S^T(0), dP^T(0)
 #pragma unroll
@@ -525,6 +535,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     const int nb = slot_of(st + 1);
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb;   // rows of the next stage
     if (CDIAG || more) stage_dma((st + 1) * ST, nb);   // (causal build: the two stages of the diagonal block follow the sweep)
+    else if (TILED && pass + 1 < npass) stage_dma(0, nb);   // the next query block's sweep starts over at key stage 0
     const int kb = st * ST;
     // a sub-tile needs the mask when it crosses N or (causal) this wave's first query; wave-uniform
     auto need = [&](int sub) { return MASKS && ((kb + 32 * sub + 31 >= N) || (causal && kb + 32 * sub + 31 > q0)); };
@@ -568,6 +579,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   }
   // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
   period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+  if constexpr (TILED) roff = (roff + nstage) % 3;
   if constexpr (CDIAG) {   // the stage hand-off this wave has no periods for (same DMA share, wait and barrier as in the loop)
     for (int st = nst_w; st < nst_all; ++st) {
       stage_dma((st + 1) * ST, slot_of(st + 1));
