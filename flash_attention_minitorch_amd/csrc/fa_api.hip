@@ -370,17 +370,17 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
     FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
               (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, prep ? *prep : fa::DqPrep{});
   } else if (DIAG == 0 && !causal && N % 128 == 0) {   // no sub-tile needs a mask: the build without masked period variants
-    // Several consecutive query blocks of a head per workgroup (the tiled build: no set-up, no wait for the first stage, no store
-    // drain between them) while the grid still covers every CU; option 5 = 1: one block per workgroup
+    // Query block qb of several consecutive heads per workgroup (the tiled build: no set-up, no wait for the first stage, no store
+    // drain between them) while the grid still covers every CU (the rule of the tiled dK/dV launch); option 5 = 1: one head
     int tiles = 1;
     if (N % 256 == 0 && tun.v[5] == 0) {
       const int cus = std::max(device_cus(), 1);
       for (int t = 2; t <= 16; ++t)
-        if (nqb % t == 0 && (long)batch * (nqb / t) >= cus) tiles = t;
+        if (batch % t == 0 && (batch / t) % 8 == 0 && (long)(batch / t) * nqb >= cus) tiles = t;
     }
     if (tiles > 1) {
       lay.tiles = tiles;
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3(batch * (nqb / tiles)), dim3(512), 0, st, (const T*)q,
+      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3((batch / tiles) * nqb), dim3(512), 0, st, (const T*)q,
                 (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, prep ? *prep : fa::DqPrep{});
     } else {
       FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,

@@ -119,8 +119,8 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[4]  1 = keep the separate preprocess kernel (default: the dQ launch preprocesses its own rows, writes the workspace and runs
  *            BEFORE the dK/dV launch; same results up to summation order of delta)
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
- *            per workgroup when the launch still covers every CU) and the non-causal d = 64 dQ kernel one query block per workgroup
- *            (default: several consecutive query blocks of a head, same condition); bitwise the same results
+ *            per workgroup when the launch still covers every CU), and so does the non-causal d = 64 dQ kernel (default: query block
+ *            qb of several consecutive heads, same condition); bitwise the same results
  *   opts[6]  (diagnostic library only)
  *   opts[7]  block order of causal launches: 1 = query blocks p and nqb-1-p paired in one workgroup (slot and phased forward / dQ
  *            kernels) and head-by-head order for the unpaired dK/dV launches (fp32 d = 64, bf16 d = 128); 2 = one block per

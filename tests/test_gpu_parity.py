@@ -422,8 +422,8 @@ def test_forward_slot_kernel_d128(dev, N):
 def test_tiled_dkdv_build_is_bitwise_the_one_head_build(dev, BH, N):
     """bf16, d = 64, non-causal, N a multiple of 256, launches of at least one workgroup per CU per head group: the dK/dV slot
     kernel's tiled build (key block kb of 2 / 2 / 4 / 5 / 8 consecutive heads per workgroup, the ring and the pipeline carried from
-    head to head) and the dQ slot kernel's (2 / 1 / 4 / 4 / 8 consecutive query blocks of a head per workgroup, round 3) against the
-    one-block-per-workgroup builds (option 5 = 1): the same arithmetic in the same order, so bit for bit; two heads (the first of a
+    head to head) and the dQ slot kernel's (query block qb of as many consecutive heads per workgroup, round 3) against the
+    one-head-per-workgroup builds (option 5 = 1): the same arithmetic in the same order, so bit for bit; two heads (the first of a
     group and the last one) against the oracle."""
     import torch
     rng = np.random.default_rng(9100 + BH + N)
