@@ -98,6 +98,8 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_bwd_dropout.restype = _i
     h.fa_mi355x_bwd_workspace_bytes.argtypes = [_i, _i, _i]
     h.fa_mi355x_bwd_workspace_bytes.restype = ctypes.c_size_t
+    h.fa_mi355x_bwd_workspace_bytes_ex.argtypes = [_i, _i, _i, ctypes.POINTER(ctypes.c_int), _i]
+    h.fa_mi355x_bwd_workspace_bytes_ex.restype = ctypes.c_size_t
     h.fa_mi355x_last_error.argtypes = []
     h.fa_mi355x_last_error.restype = ctypes.c_char_p
     h.fa_mi355x_version.argtypes = []

@@ -123,6 +123,32 @@ int device_cus() {   // compute units of the current device (cached per device; 
   return cus[dev];
 }
 
+// ---- the chained one-pass backward (bwd_chain_kernel: bf16, d = 64, non-causal, N a multiple of 256; DIAGNOSTIC BUILD ONLY: it
+// measured slower than the two-kernel backward, profiles/r04_chain_backward.txt, and keeps 36 B of scratch per lane) ---------------
+// A workgroup takes C = nkb / nchains consecutive key blocks of one (batch*head); nchains = the smallest divisor of nkb = N / 256
+// that fills the chip (batch * nchains >= CUs), all of them if none does.  nchains == 1: dq carries the running sums, no atomics,
+// no workspace beyond the 4-KiB header; otherwise a private slab of N * 64 floats per workgroup and fp32 atomics from each chain's
+// last key block into a zero-filled dq.
+inline bool chain_shape(int N, int d) { return d == 64 && N >= 256 && N % 256 == 0; }
+inline int chain_count(int batch, int N, int cus) {
+  const int nkb = N / 256;
+  if (cus <= 0) cus = 256;
+  for (int n = 1; n <= nkb; ++n)
+    if (nkb % n == 0 && (long)batch * n >= cus) return n;
+  return nkb;
+}
+#ifdef FA_DIAG
+inline size_t chain_extra_bytes(int batch, int N, int d, int cus) {
+  if (!chain_shape(N, d)) return 0;
+  const int nchains = chain_count(batch, N, cus), nkb = N / 256;
+  size_t b = fa::CHAIN_HDR;
+  if (nchains > 1 && nchains < nkb) b += (size_t)batch * nchains * (size_t)N * 256u;
+  return b;
+}
+#else
+inline size_t chain_extra_bytes(int, int, int, int) { return 0; }
+#endif
+
 // Causal slot builds: heads per XCD dispatched together, longest block first (fa::map_block_ranked): a chunk of two rounds of the chip
 int rank_chunk(int wgs_per_cu, int nb) {
   const int cus = device_cus();
@@ -539,6 +565,46 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     }
   }
 #endif   // FA_DIAG: one-pass backward
+#ifdef FA_DIAG
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    // Option 4 = 3: the chained one-pass backward (five products instead of seven; fa_bwd_chain.h).
+    const int both = FA_BWD_STAGE_DKDV | FA_BWD_STAGE_DQ;
+    if ((stages & both) == both && tun.v[4] == 3 && chain_shape(N, D) && !causal && !lay.kmask && !lay.drop_thr) {
+      const int nkb = N / 256, nchains = chain_count(batch, N, device_cus());
+      float* slab = (float*)((char*)ws + align256z((size_t)WS_VECS * rows * sizeof(float)));
+      const dim3 grid((unsigned)(batch * nchains));
+#define FA_CHAIN_LAUNCH(ATOMIC, ABL)                                                                                         \
+  FA_LAUNCH((fa::bwd_chain_kernel<T, 64, ATOMIC, ABL>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v,       \
+            (const T*)dout, nl2, delta, dq, dk, dv, slab, N, nkb, batch, nchains, lay, tau)
+      if (nchains > 1) {
+        // every chain's last key block ADDS tau * (its sum) to dq (the reference's caller zeroes q_grad for its atomicAdd as well:
+        // minitorch/cuda_kernel_ops.py:609-611); [B][N][H][d] or [BH][N][d]: the tensor is one contiguous range either way
+        FA_HIP_TRY(hipMemsetAsync(dq, 0, (size_t)rows * D * sizeof(float), st));
+        switch (tun.v[5]) {   // timing ablations (WRONG results): see bwd_chain_kernel
+          case 1: FA_CHAIN_LAUNCH(true, 1); break;
+          case 2: FA_CHAIN_LAUNCH(true, 2); break;
+          case 3: FA_CHAIN_LAUNCH(true, 3); break;
+          case 64: FA_CHAIN_LAUNCH(true, 64); break;
+          case 128: FA_CHAIN_LAUNCH(true, 128); break;
+          case 256: FA_CHAIN_LAUNCH(true, 256); break;
+          case 512: FA_CHAIN_LAUNCH(true, 512); break;
+          case 1024: FA_CHAIN_LAUNCH(true, 1024); break;
+          case 1536: FA_CHAIN_LAUNCH(true, 1536); break;
+          case 2048: FA_CHAIN_LAUNCH(true, 2048); break;
+          case 2304: FA_CHAIN_LAUNCH(true, 2304); break;
+          case 4352: FA_CHAIN_LAUNCH(true, 4352); break;
+          case 8448: FA_CHAIN_LAUNCH(true, 8448); break;
+          default: FA_CHAIN_LAUNCH(true, 0); break;
+        }
+      } else {
+        FA_CHAIN_LAUNCH(false, 0);
+      }
+#undef FA_CHAIN_LAUNCH
+      FA_HIP_TRY(hipGetLastError());
+      return FA_OK;
+    }
+  }
+#endif   // FA_DIAG: chained one-pass backward
   if (stages & FA_BWD_STAGE_DKDV) {
     int rc;
     if constexpr (sizeof(T) == 2 && D <= 64) {
@@ -1182,6 +1248,14 @@ size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d) {
   const size_t rowc = (size_t)WS_VECS * batch * N * sizeof(float);
   const size_t extra = fused_extra_bytes(batch, N, d);
   return extra ? align256z(rowc) + extra : rowc;
+}
+
+size_t fa_mi355x_bwd_workspace_bytes_ex(int batch, int N, int d, const int* opts, int nopts) {
+  const size_t plain = fa_mi355x_bwd_workspace_bytes(batch, N, d);
+  if (!plain || !opts || nopts < 5 || opts[4] != 3) return plain;
+  const size_t rowc = (size_t)WS_VECS * batch * N * sizeof(float);
+  const size_t extra = chain_extra_bytes(batch, N, d, device_cus());
+  return std::max(plain, extra ? align256z(rowc) + extra : rowc);
 }
 
 int fa_mi355x_bwd_status(const void* workspace, int batch, int N, int d, int* status) {

@@ -36,5 +36,6 @@
 #include "fa_bwd_dq.h"
 #ifdef FA_DIAG
 #include "fa_bwd_fused.h"   // the one-pass backward: diagnostic build only (tools/check_fused.py)
+#include "fa_bwd_chain.h"   // its round-4 form (chained key blocks, fp32 atomics from the last one): tools/check_chain.py
 #endif
 #include "fa_aux.h"

@@ -69,6 +69,10 @@ def pick_opts(q, k, budget=1e-2):
     est = float(qn * kn) * (1.4426950408889634 / d ** 0.5) * (2.0 ** -9) / 3.0 ** 0.5
     return OPTS_EXACT_SCALE if est > budget else None
 OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # DIAGNOSTIC LIBRARY ONLY (tools/check_fused.py): dQ inside the key-stationary kernel, ordered hand-off
+# DIAGNOSTIC LIBRARY ONLY (tools/check_chain.py): the chained one-pass backward (bf16, d = 64, non-causal, N % 256 == 0): five products
+# instead of seven, the running dQ tiles carried through memory along a workgroup's key blocks, fp32 atomics only from each chain's last
+# block (none when B*H >= CUs).  Measured 2-5 % slower than the two-kernel default from N = 2048 up (profiles/r04_chain_backward.txt).
+OPTS_CHAINED_BWD = (0, 0, 0, 0, 3)
 
 
 _NATIVE_D = (32, 64, 128)
@@ -119,15 +123,20 @@ def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None,
     return out, l, m
 
 
-def _workspace(bh, n, d, device):
-    nbytes = _lib.core().fa_mi355x_bwd_workspace_bytes(bh, n, d)
-    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+def _workspace_bytes(bh, n, d, opts=None):
+    arr, cnt = _lib.opts_array(opts)
+    return _lib.core().fa_mi355x_bwd_workspace_bytes_ex(bh, n, d, arr, cnt)
 
 
-def bwd_workspace(q):
-    """Scratch for the backward of (.., N, d) tensors, sized by the library (fa_mi355x_bwd_workspace_bytes)."""
+def _workspace(bh, n, d, device, opts=None):
+    return torch.empty((_workspace_bytes(bh, n, d, opts) + 3) // 4, dtype=torch.float32, device=device)
+
+
+def bwd_workspace(q, opts=None):
+    """Scratch for the backward of (.., N, d) tensors, sized by the library (fa_mi355x_bwd_workspace_bytes_ex: the chained
+    one-pass backward, OPTS_CHAINED_BWD, needs slabs for its running dQ tiles on top of the row constants)."""
     n, d = q.shape[-2], q.shape[-1]
-    return _workspace(q.numel() // (n * d), n, _padded_d(d), q.device)
+    return _workspace(q.numel() // (n * d), n, _padded_d(d), q.device, opts)
 
 
 def bwd_status(workspace, q):
@@ -163,7 +172,9 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
             dst.copy_(g[..., :d])
         return tuple(grads)
     if workspace is None:
-        workspace = bwd_workspace(q)
+        workspace = bwd_workspace(q, opts)
+    elif workspace.numel() * workspace.element_size() < _workspace_bytes(bh, n, d, opts):
+        raise ValueError("workspace too small for these options: size it with bwd_workspace(q, opts)")
     if grads is None:
         grads = tuple(torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
     dq, dk, dv = grads

@@ -82,6 +82,12 @@ int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float
  * backward entry point below expects a workspace of at least this size. */
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
 
+/* The same for a backward call with per-call options (fa_mi355x_bwd_ex).  Product library: fa_mi355x_bwd_workspace_bytes.  Diagnostic
+ * library: opts[4] = 3 (the chained one-pass backward) adds a 4-KiB header and, when its chains do not cover whole heads (batch < CUs),
+ * one slab of N * 64 floats per workgroup: batch * nchains * N * 256 bytes with nchains = the smallest divisor of N / 256 that gives
+ * batch * nchains >= CUs (256 MiB at batch 64, N 4096 on 256 CUs). */
+size_t fa_mi355x_bwd_workspace_bytes_ex(int batch, int N, int d, const int* opts, int nopts);
+
 /* Synchronous check of the one-pass backward's error word in a workspace the last backward call used: *status = 0 if no
  * hand-off wait timed out (always 0 for shapes / calls that ran the two-kernel backward).  Returns FA_ERR_HIP and a
  * message when it is non-zero (the gradients of that call are then invalid).  The one-pass kernel is a persistent grid
@@ -117,7 +123,12 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[2]  dQ kernel: 2 = phased with 32-key tiles (fp32 scaling), 3 = slot kernel also under the causal mask
  *   opts[3]  (diagnostic library only)
  *   opts[4]  1 = keep the separate preprocess kernel (default: the dQ launch preprocesses its own rows, writes the workspace and runs
- *            BEFORE the dK/dV launch; same results up to summation order of delta)
+ *            BEFORE the dK/dV launch; same results up to summation order of delta);
+ *            (diagnostic library only: 2 = the one-pass backward with an ordered hand-off, round 2; 3 = the CHAINED one-pass backward,
+ *            round 4: bf16, d = 64, non-causal, N a multiple of 256: the five products of src/flash_attn2_bw.cu:94-247 in one
+ *            key-stationary kernel, a workgroup carrying its running dQ tiles through memory along N / (256 * nchains) consecutive key
+ *            blocks and, with nchains > 1, adding to a zero-filled q_grad with fp32 atomics from the last one, the reference's scheme at
+ *            :228.  Both measured slower than the two-kernel default: profiles/r04_chain_backward.txt)
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
  *            per workgroup when the launch still covers every CU), and so does the non-causal d = 64 dQ kernel (default: query block
  *            qb of several consecutive heads, same condition); bitwise the same results
@@ -126,8 +137,8 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *            kernels) and head-by-head order for the unpaired dK/dV launches (fp32 d = 64, bf16 d = 128); 2 = one block per
  *            workgroup dispatched longest first across a chunk of heads, everywhere; 0 = per kernel what measured faster (slot
  *            builds: ranked below 8 rounds of the chip; phased forward / dQ: paired; unpaired dK/dV: ranked)
- * Values that lost their A/B in rounds 1-2 (opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1, opts[4] = 2 = the one-pass
- * backward, opts[6] = 1) exist in the diagnostic library only; the product library answers them with FA_ERR_BAD_ARG.
+ * Values that lost their A/B (opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1, opts[4] = 2 / 3 = the one-pass
+ * backwards, opts[6] = 1) exist in the diagnostic library only; the product library answers them with FA_ERR_BAD_ARG.
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
  * library (FA_ERR_BAD_ARG).  `stages` as fa_mi355x_bwd_stages. */
 int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,

@@ -143,6 +143,12 @@ def test_argument_validation_without_gpu(built):
     assert core.fa_mi355x_bwd_workspace_bytes(64, 4100, 64) == 3 * 64 * 4100 * 4      # not a one-pass shape
     assert core.fa_mi355x_bwd_workspace_bytes(64, 4096, 64) == 3 * 64 * 4096 * 4
     assert core.fa_mi355x_bwd_workspace_bytes(0, 4096, 64) == 0
+    # with options: the product library has no kernel that needs more (the chained one-pass backward, opts[4] = 3, whose slabs this
+    # entry point sizes, lives in the diagnostic library)
+    core.fa_mi355x_bwd_workspace_bytes_ex.restype = ctypes.c_size_t
+    chain = (ctypes.c_int * 5)(0, 0, 0, 0, 3)
+    assert core.fa_mi355x_bwd_workspace_bytes_ex(64, 4096, 64, chain, 5) == 3 * 64 * 4096 * 4
+    assert core.fa_mi355x_bwd_workspace_bytes_ex(64, 4096, 64, None, 0) == 3 * 64 * 4096 * 4
     # per-call options: diagnostic values are rejected by the product library before any HIP call
     bad = (ctypes.c_int * 3)(93, 0, 0)
     assert core.fa_mi355x_fwd_ex(one, one, one, one, one, one, 1, 16, 64, 0, 2, 0, bad, 3, null) == 1

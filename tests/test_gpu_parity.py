@@ -576,6 +576,22 @@ def test_one_pass_backward_in_the_diagnostic_library():
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_chained_one_pass_backward_in_the_diagnostic_library():
+    """Round 4: the five-product backward of the reference (src/flash_attn2_bw.cu:94-247: S, dP, dV, dK, dQ in ONE
+    key-stationary pass, dQ summed over key blocks with atomicAdd at :228) as csrc/fa_bwd_chain.h builds it: a workgroup takes
+    consecutive key blocks of a head and carries its running dQ tiles through memory; fp32 atomics only from the last block of each
+    chain, none when a workgroup covers a whole head.  It measured slower than the two-kernel backward (profiles/r04_chain_backward.txt)
+    and keeps 36 B of scratch, so it lives in the diagnostic build.  tools/check_chain.py, run as a CHILD process, checks it at eight
+    shapes (1-4 chains per head, 1-16 blocks per chain, B=8 H=8 N=4096 among them) against the fp64 oracle (1e-3), the two-kernel
+    backward (2e-3) and itself (run to run: 1e-5; the atomics' arrival order moves dq in the last bits only)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FA_MI355X_DIAG="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_chain.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype,d", [("f32", 64), ("bf16", 128), ("bf16", 32)])
 @pytest.mark.parametrize("N", [33, 200])
 def test_ragged_tail_with_very_negative_logsumexp(dev, dtype, d, N):
