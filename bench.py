@@ -67,12 +67,33 @@ def parse():
     return ap.parse_args()
 
 
-def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd):
+def with_scale_mode(opts, mode):
+    o = list(opts or ()) + [0] * 9
+    o[8] = mode
+    return tuple(o[:max(9, len(opts or ()))])
+
+
+def guarded_call(BH, N, d, causal, dtype, opts):
+    """Does the default call of this shape run under the scale guard (a kernel with the folded softmax scale AND its fp32-scaling
+    twin are launched, include/flash_attn_mi355x.h)?  Asked of the library: the plan of a guarded call names more launches."""
+    from flash_attention_minitorch_amd import _lib
+    if opts is not None and len(opts) > 8 and opts[8] != 0:
+        return False
+    dt = _lib.FA_DTYPE_BF16 if dtype == "bf16" else _lib.FA_DTYPE_F32
+    one = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0, with_scale_mode(opts, 1))
+    two = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0, with_scale_mode(opts, 3))
+    return len(two) > len(one)
+
+
+def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd, guard_fn=None):
     """The step as a list of (kernel name, callable) in the library's own launch order, from fa_mi355x_plan.  A backward plan without
-    bwd_prep_kernel means the dQ launch preprocesses its own rows and runs first; bwd_fused_kernel is the opt-in one-pass backward."""
+    bwd_prep_kernel means the dQ launch preprocesses its own rows and runs first; bwd_fused_kernel is the opt-in one-pass backward.
+    guard_fn (a guarded step): the scale-guard pass comes first, and every stage is the launch of the named kernel plus the launch of
+    its fp32-scaling twin, which returns at once for operands inside the guard's budget (the names are those of the chosen side)."""
     from flash_attention_minitorch_amd import _lib
     dt = _lib.FA_DTYPE_BF16 if dtype == "bf16" else _lib.FA_DTYPE_F32
-    plan = lambda stages: _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, stages, opts)
+    popts = with_scale_mode(opts, 1) if guard_fn is not None else opts
+    plan = lambda stages: _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, stages, popts)
     main = lambda names: [n for n in names if n != "bwd_prep_kernel"][0]   # (a follow-up launch of the same kernel follows its main one)
     k_fwd = main(plan(0))
     whole = plan(device_ops.STAGE_ALL)
@@ -86,6 +107,8 @@ def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd):
     else:
         stages = ((k_fwd, fwd), (k_dq, lambda: bwd(device_ops.STAGE_PREP | device_ops.STAGE_DQ)),
                   (k_dkdv, lambda: bwd(device_ops.STAGE_DKDV)))
+    if guard_fn is not None:
+        stages = (("scale_guard_kernel", guard_fn),) + stages
     return stages, k_fwd, k_dq, k_dkdv
 
 
@@ -100,11 +123,17 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
     o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal)
     ws = device_ops.bwd_workspace(q)
     grads = tuple(torch.empty(q.shape, dtype=torch.float32, device="cuda") for _ in range(3))
-    f_fw = lambda: device_ops.flash_attn_fwd(q, k, v, causal, out=o, l=L)
+    # (the default calls run under the scale guard: its pass over q, k belongs to the forward; the backward takes the same guard)
+    g0 = device_ops._auto_guard(q, k, None, "auto")
+
+    def f_fw():
+        if g0 is not None:
+            device_ops.scale_guard(q, k, out=g0)
+        device_ops.flash_attn_fwd(q, k, v, causal, out=o, l=L, guard=g0)
 
     def f_fwbw():
         f_fw()
-        device_ops.flash_attn_bwd(q, k, v, o, do, L, None, causal, workspace=ws, grads=grads)
+        device_ops.flash_attn_bwd(q, k, v, o, do, L, None, causal, workspace=ws, grads=grads, guard=g0)
 
     v_fw = lambda: vg.vanilla_attention(q, k, v, causal)
     v_fwbw = lambda: vg.vanilla_fw_bw(q, k, v, do, causal)
@@ -144,7 +173,14 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
         mk = lambda: ((torch.rand((BH_, N_, d_), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
         qq, kk, vv = mk(), mk(), mk()
         oo, ll, _ = device_ops.flash_attn_fwd(qq, kk, vv, False)
-        tf = vg.time_ms(lambda: device_ops.flash_attn_fwd(qq, kk, vv, False, out=oo, l=ll), 20, 5)
+        gg = device_ops._auto_guard(qq, kk, None, "auto")
+
+        def one():
+            if gg is not None:
+                device_ops.scale_guard(qq, kk, out=gg)
+            device_ops.flash_attn_fwd(qq, kk, vv, False, out=oo, l=ll, guard=gg)
+
+        tf = vg.time_ms(one, 20, 5)
         tfl = 4.0 * BH_ * N_ * N_ * d_ / tf / 1e9
         return {"ms_tflops_frac": [round(tf, 4), round(tfl, 1), round(tfl / PEAK_BF16_TFLOPS, 4)]}
 
@@ -155,8 +191,14 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
         oo, ll, mm = device_ops.flash_attn_fwd(qq, kk, vv, caus, variant)
         w2 = device_ops.bwd_workspace(qq)
         gg = tuple(torch.empty(qq.shape, dtype=torch.float32, device="cuda") for _ in range(3))
-        fw = lambda: device_ops.flash_attn_fwd(qq, kk, vv, caus, variant, out=oo, l=ll, m=mm)
-        bw = lambda: device_ops.flash_attn_bwd(qq, kk, vv, oo, dd, ll, mm, caus, variant, workspace=w2, grads=gg)
+        gd = device_ops._auto_guard(qq, kk, None, "auto")
+
+        def fw():
+            if gd is not None:
+                device_ops.scale_guard(qq, kk, out=gd)
+            device_ops.flash_attn_fwd(qq, kk, vv, caus, variant, out=oo, l=ll, m=mm, guard=gd)
+
+        bw = lambda: device_ops.flash_attn_bwd(qq, kk, vv, oo, dd, ll, mm, caus, variant, workspace=w2, grads=gg, guard=gd)
         tf, tb = vg.time_ms(fw, iters, warm), vg.time_ms(bw, iters, warm)
         cf = 0.5 if caus else 1.0
         fl_fw, fl_bw = 4.0 * B * H * N_ * N_ * d_ * cf, 10.0 * B * H * N_ * N_ * d_ * cf
@@ -336,17 +378,25 @@ def main():
     grads = tuple(torch.empty((BH, N, d), dtype=torch.float32, device="cuda") for _ in range(3))
     ws = device_ops.bwd_workspace(q)
 
+    # The default call runs under the scale guard (include/flash_attn_mi355x.h): ONE pass over q and k per step (inside the timed
+    # region: a training step sees new q, k every time), whose result the forward and the backward launches read on the device.
+    GUARDED = guarded_call(BH, N, d, causal, args.dtype, OPTS)
+    guard = device_ops.scale_guard(q, k) if GUARDED else None
+
+    def guard_pass():
+        device_ops.scale_guard(q, k, out=guard)
+
     def fwd():
-        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L, opts=OPTS)
+        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L, opts=OPTS, guard=guard)
 
     def bwd(stages=device_ops.STAGE_ALL):
-        device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages, opts=OPTS)
+        device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages, opts=OPTS, guard=guard)
 
     # One step = forward + backward; the backward's kernels are launched one by one so that a HIP event can be recorded between
     # kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).  Which kernels those are, and in which
     # order, is asked of the library (fa_mi355x_plan runs its dispatch code with the launches skipped): kernel names as rocprofv3
     # shows them (fa::<name><...>).
-    STAGES, K_FWD, K_DQ, K_DKDV = stage_plan(device_ops, BH, N, d, causal, args.dtype, OPTS, fwd, bwd)
+    STAGES, K_FWD, K_DQ, K_DKDV = stage_plan(device_ops, BH, N, d, causal, args.dtype, OPTS, fwd, bwd, guard_pass if GUARDED else None)
     breakdown = not args.no_kernel_breakdown
 
     def step(ev=None, only=-1):
@@ -422,7 +472,7 @@ def main():
     if breakdown:
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
-        alg = {K_FWD: flops_fw, "bwd_prep_kernel": 0.0, K_DKDV: 8.0 * BH * N * N * d * cf,
+        alg = {"scale_guard_kernel": 0.0, K_FWD: flops_fw, "bwd_prep_kernel": 0.0, K_DKDV: 8.0 * BH * N * N * d * cf,
                K_DQ: 2.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw}
         for i, (name, _) in enumerate(STAGES):   # the dominant kernel: from the timed region; the others: the pass before it
             evs = events if i == dom_stage else pre_events
@@ -539,6 +589,13 @@ def main():
             "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
             "kernels_ms_source": "HIP events: roofline.kernel inside the timed region (two events per step); the others over the "
                                  "same number of untimed steps just before the warm-up (an event per kernel boundary)",
+            "kernels_ms_sum_note": "the entries come from two passes (see kernels_ms_source) and the untimed pass carries an event at "
+                                   "every kernel boundary (~3 us each): their sum is NOT ms_per_step and may exceed it by a few us",
+            "scale_guard": {"guarded": GUARDED,
+                            "what": "the step starts with scale_guard_kernel (one pass over q, k); the forward, dQ and dK/dV stages "
+                                    "each launch the named kernel and its fp32-scaling twin, which returns at once for operands "
+                                    "inside the guard's budget: both launches are inside the stage's time"
+                                    if GUARDED else "no kernel of this call folds the softmax scale into an operand"},
             "settle_ms": round(settle_ms, 1),
             "ms_per_step_blocks": blocks_ms,
             "ms_per_step_median": med_ms,

@@ -119,6 +119,14 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_fwd_padded.restype = _i
     h.fa_mi355x_bwd_padded.argtypes = [_vp] * 11 + [_i] * 7 + [_vp]
     h.fa_mi355x_bwd_padded.restype = _i
+    h.fa_mi355x_guard_bytes.argtypes = []
+    h.fa_mi355x_guard_bytes.restype = ctypes.c_size_t
+    h.fa_mi355x_scale_guard.argtypes = [_vp, _vp, ctypes.c_long, _i, _i, _vp, _vp]
+    h.fa_mi355x_scale_guard.restype = _i
+    h.fa_mi355x_fwd_guarded.argtypes = [_vp] * 6 + [_i] * 5 + [ctypes.c_float] + [_i] * 3 + [_ip, _i, _vp, _vp]
+    h.fa_mi355x_fwd_guarded.restype = _i
+    h.fa_mi355x_bwd_guarded.argtypes = [_vp] * 11 + [_i] * 5 + [ctypes.c_float] + [_i] * 4 + [_ip, _i, _vp, _vp]
+    h.fa_mi355x_bwd_guarded.restype = _i
     h.fa_mi355x_plan.argtypes = [_i] * 7 + [_ip, _i, ctypes.c_char_p, ctypes.c_size_t]
     h.fa_mi355x_plan.restype = _i
     if DIAG:

@@ -42,7 +42,10 @@ int set_err(int code, const char* what, hipError_t e = hipSuccess) {
 // recorder installed: the launch is then skipped and the kernel's name appended to the plan, so what bench.py labels and what the
 // library launches cannot drift apart (one source of truth for the kernel selection).
 thread_local std::vector<std::string>* t_plan = nullptr;
-bool plan_mode() { return t_plan != nullptr; }
+// A second dry-run mode, for run_scaled below: the dispatch code runs with every launch and HIP call skipped and nothing recorded but
+// t_fold: did the selection reach a kernel that carries tau*log2(e) in a bf16 operand (FA_LAUNCH_FOLD sites)?
+thread_local bool t_probe = false, t_fold = false;
+bool plan_mode() { return t_plan != nullptr || t_probe; }
 void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> "fwd_slot_kernel"
   const char* b = expr;
   while (*b == '(' || *b == ' ') ++b;
@@ -53,8 +56,15 @@ void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> 
 }
 #define FA_LAUNCH(kern, grid, block, shmem, st, ...)                        \
   do {                                                                      \
+    if (t_probe) break;                                                     \
     if (t_plan) plan_add(#kern);                                            \
     else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);     \
+  } while (0)
+// ... of a kernel whose lane-stationary bf16 operand carries tau*log2(e) (the MFMA-slot builds without masked periods)
+#define FA_LAUNCH_FOLD(kern, grid, block, shmem, st, ...)                   \
+  do {                                                                      \
+    t_fold = true;                                                          \
+    FA_LAUNCH(kern, grid, block, shmem, st, __VA_ARGS__);                   \
   } while (0)
 
 inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
@@ -64,26 +74,32 @@ inline int d_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
 // [1] forward kernel, [2] dQ kernel, [3] 1 = s_setprio 1 for waves 4-7 of the slot kernels, [4] 2 = one-pass backward, [5] (FA_DIAG
 // builds only) timing ablations of the one-pass backward, [6] 1 = causal d = 64 forward / dK/dV as main build + follow-up launch (A/B).  The product library accepts only values whose kernels give correct
 // results; stamp builds, A/B staging variants and ablations exist in the FA_DIAG build alone (libflash_attn_mi355x_diag.so, tools/).
-struct Tun { int v[8]; };
+// [8] where tau*log2(e) is applied (see run_scaled): 0 = by the call's scale guard when it has one, else fp32 scaling; 1 = the caller
+// vouches for the operand range (inputs of the north star's U(-1, 1) magnitude): the kernels that fold it into a bf16 operand run
+// without a guard; 2 = fp32 scaling whatever the guard says; 3 = (fa_mi355x_plan only) plan a guarded call.  [9] unused.
+constexpr int NTUN = 10;
+struct Tun { int v[NTUN]; };
 #ifdef FA_DIAG
-int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // fa_mi355x_set_tuning(): process-wide defaults of the diagnostic build
+// fa_mi355x_set_tuning(): process-wide defaults of the diagnostic build (its tools time and stamp the folded-scale kernels: [8] = 1)
+int g_tuning[NTUN] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
 #endif
 inline Tun default_tun() {
-  Tun t = {{0, 0, 0, 0, 0, 0, 0, 0}};
+  Tun t = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 #ifdef FA_DIAG
-  for (int i = 0; i < 8; ++i) t.v[i] = g_tuning[i];
+  for (int i = 0; i < NTUN; ++i) t.v[i] = g_tuning[i];
 #endif
   return t;
 }
 int parse_opts(const int* opts, int nopts, Tun& t) {
   t = default_tun();
-  if (nopts < 0 || nopts > 8 || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
+  if (nopts < 0 || nopts > NTUN || (nopts > 0 && !opts)) return set_err(FA_ERR_BAD_ARG, "bad options array");
   for (int i = 0; i < nopts; ++i) t.v[i] = opts[i];
 #ifndef FA_DIAG
   // (round 3 library diet: the values that lost their A/B and had no test -- opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1,
   // opts[4] = 2 (the one-pass backward), opts[6] = 1 -- exist in the diagnostic build only, together with their kernels)
-  static const int allowed[8][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1}};
-  for (int i = 0; i < 8; ++i) {
+  static const int allowed[NTUN][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1},
+                                       {0, 1, 2, 3, -1}, {0, -1}};
+  for (int i = 0; i < NTUN; ++i) {
     bool ok = false;
     for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
     if (!ok) return set_err(FA_ERR_BAD_ARG, "option value not available in the product library (diagnostic builds only)");
@@ -215,13 +231,13 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       const bool whole = !causal && N % (8192 / D) == 0;   // no sub-tile needs a mask
 #ifdef FA_DIAG
       if (whole && tun.v[1] == 94) {   // timing ablation: no per-stage barrier (WRONG results)
-        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false, 2, 64, (D == 64 ? 4 : 2)>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, D, false, 2, 64, (D == 64 ? 4 : 2)>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
       if (whole && tun.v[1] == 93) {   // phase stamps (never timed)
-        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false, 1, 64, (D == 64 ? 4 : 2)>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, D, false, 1, 64, (D == 64 ? 4 : 2)>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
@@ -230,7 +246,7 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
       if (cslot) {   // (d = 64: four waves per SIMD, two workgroups per CU; d = 128: two waves per SIMD, one workgroup)
         const bool ranked = causal_ranked(tun, batch * nqb, D == 64 ? 2 : 1);
         lay.rank_chunk = rank_chunk(D == 64 ? 2 : 1, nqb);
-        FA_LAUNCH((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>),
+        FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, D, false, 0, 64, (D == 64 ? 4 : 2), true>),
                            dim3(ranked ? batch * nqb : batch * ((nqb + 1) / 2)),
                            dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, ranked ? 2 : 1, tau);
         FA_HIP_TRY(hipGetLastError());
@@ -243,14 +259,14 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
 #endif
       if (whole && (tun.v[1] != 6 || !diag_stk) && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)
-        FA_LAUNCH((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
       if constexpr (D == 128 || diag_stk) {
         if (whole) {
-          FA_LAUNCH((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+          FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                              (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
           FA_HIP_TRY(hipGetLastError());
           return FA_OK;
@@ -393,7 +409,7 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
   if (DIAG == 0 && causal && N % 256 == 0) {   // causal build: unmasked sweep + the diagonal block per wave; one block per workgroup,
     // longest first across all heads (paired: blocks p and nqb-1-p in one workgroup)
     const dim3 grid(paired ? batch * ((nqb + 1) / 2) : batch * nqb);
-    FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+    FA_LAUNCH_FOLD((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
               (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, prep ? *prep : fa::DqPrep{});
   } else if (DIAG == 0 && !causal && N % 128 == 0) {   // no sub-tile needs a mask: the build without masked period variants
     // Query block qb of several consecutive heads per workgroup (the tiled build: no set-up, no wait for the first stage, no store
@@ -406,10 +422,10 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
     }
     if (tiles > 1) {
       lay.tiles = tiles;
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3((batch / tiles) * nqb), dim3(512), 0, st, (const T*)q,
+      FA_LAUNCH_FOLD((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3((batch / tiles) * nqb), dim3(512), 0, st, (const T*)q,
                 (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, prep ? *prep : fa::DqPrep{});
     } else {
-      FA_LAUNCH((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+      FA_LAUNCH_FOLD((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                 (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, prep ? *prep : fa::DqPrep{});
     }
   } else {
@@ -574,7 +590,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       float* slab = (float*)((char*)ws + align256z((size_t)WS_VECS * rows * sizeof(float)));
       const dim3 grid((unsigned)(batch * nchains));
 #define FA_CHAIN_LAUNCH(ATOMIC, ABL)                                                                                         \
-  FA_LAUNCH((fa::bwd_chain_kernel<T, 64, ATOMIC, ABL>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v,       \
+  FA_LAUNCH_FOLD((fa::bwd_chain_kernel<T, 64, ATOMIC, ABL>), grid, dim3(512), 0, st, (const T*)q, (const T*)k, (const T*)v,       \
             (const T*)dout, nl2, delta, dq, dk, dv, slab, N, nkb, batch, nchains, lay, tau)
       if (nchains > 1) {
         // every chain's last key block ADDS tau * (its sum) to dq (the reference's caller zeroes q_grad for its atomicAdd as well:
@@ -629,7 +645,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (D == 64 && !causal && tun.v[0] == 193 && !lay.drop_thr) {   // continuous slot pipeline with phase stamps
         const int nkb = (N + 255) / 256;
-        FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
@@ -649,10 +665,10 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         }
         if (tiles > 1) {
           lay.tiles = tiles;
-          FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
+          FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
                              (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         } else {
-          FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+          FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                              (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         }
         FA_HIP_TRY(hipGetLastError());
@@ -663,7 +679,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // diagonal block, the block per wave, workgroups longest first); tuning key 0 = 3: the phased kernel below
         const int nkb = N / 256;
         lay.rank_chunk = rank_chunk(1, nkb);
-        FA_LAUNCH((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
@@ -746,20 +762,80 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
 fa::Layout bhnd(int N, int dp) { return fa::Layout{1, dp, (long)N * dp, 0, nullptr, 1, 0u, 1.0f, 0u, 0}; }
 fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H * dp, (long)dp, nullptr, 1, 0u, 1.0f, 0u, 0}; }
 
+// ---- where tau*log2(e) is applied (round 4) -------------------------------------------------------------------------------------
+// The MFMA-slot kernels fold c = tau*log2(e) into one bf16 operand (one more 2^-9 relative rounding of q or k, worth 8-10 % of the
+// step); everything else scales each score in fp32, as the reference does (src/flash_attn2_fw.cu:152-167).  The fold is invisible at
+// the north star's U(-1, 1) inputs and grows with the square of the input magnitude (x2: 1.4e-3 on O against 0.7e-3; x6: 3.6e-2
+// against 3.6e-3, profiles/r03_prescale_accuracy.txt), so it needs evidence about the operands:
+//   * a call WITH a scale guard (fa_mi355x_scale_guard: one pass over q and k on the device, no host synchronisation) launches the
+//     selected kernels AND their fp32-scaling twins; every workgroup evaluates the guard on entry and the launch on the wrong side of
+//     the budget returns at once (fa_common.h: guard_skip).  Estimate: 2^-9 / sqrt(3) * c * max_rows |q| * max_rows |k| against
+//     GUARD_BUDGET (log2 units): U(-1, 1) gives 5.7e-3 at d = 64 and 7e-3 at d = 128, inputs 1.3x larger go to fp32 scaling.
+//   * a call WITHOUT one runs the fp32-scaling kernels (options 0 / 1 / 2 at 4 / 2 / 2), unless
+//     option 8 = 1 (the caller vouches for the range), the selection folds nothing anyway (fp32, d = 32, key mask, dropout, ragged N:
+//     probed with a dry run of the dispatch code), or c is 1 (softmax_scale = ln 2: the operand multiply is exact).
+constexpr float GUARD_BUDGET = 1e-2f;
+inline Tun exact_tun(Tun t) {   // the kernels that scale every score in fp32 (the phased builds), whatever else the caller selected
+  t.v[0] = 4;
+  t.v[1] = 2;
+  t.v[2] = 2;
+  return t;
+}
+template <class F>
+int run_scaled(F&& run, const Tun& tun, fa::Layout lay, float tau, const float* guard) {
+  const float c = tau * fa::LOG2E;
+  const int mode = tun.v[8];
+  if (mode == 1 || fabsf(c - 1.0f) < 1e-6f) return run(tun, lay);
+  if (mode == 3 && t_plan) guard = reinterpret_cast<const float*>(16);   // fa_mi355x_plan: both launches of a guarded call
+  if (!plan_mode() || t_plan) {   // does the selection fold at all?  (dry run: no launch, no HIP call, nothing recorded)
+    std::vector<std::string>* keep = t_plan;
+    t_plan = nullptr;
+    t_probe = true;
+    t_fold = false;
+    const int rc = run(tun, lay);
+    t_probe = false;
+    t_plan = keep;
+    if (rc) return rc;
+    if (!t_fold) return run(tun, lay);
+  }
+  if (mode == 2 || !guard) return run(exact_tun(tun), lay);
+  lay.guard = guard;
+  lay.guard_coef = c * (0.001953125f * 0.57735027f) / GUARD_BUDGET;
+  lay.guard_want = 0;
+  if (const int rc = run(tun, lay)) return rc;
+  lay.guard_want = 1;
+  return run(exact_tun(tun), lay);
+}
+
+int fwd_dispatch_one(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int dp,
+                     fa::Layout lay, int causal, int variant, int dtype, hipStream_t st, const Tun& tun, float tau) {
+  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st, tun);
+}
+int bwd_dispatch_one(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
+                     float* dv, const float* l, const float* m, float* ws, int batch, int N, int dp, fa::Layout lay, int causal,
+                     int variant, int dtype, int stages, hipStream_t st, const Tun& tun, float tau) {
+  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, lay, causal, variant, tau, stages, st, tun);
+}
+
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
                  int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st, const Tun& tun = default_tun(),
-                 float scale = 0.f) {
+                 float scale = 0.f, const float* guard = nullptr) {
   const float tau = scale > 0.f ? scale : sqrtf(1.0f / (float)d);   // (scale: fa_mi355x_*_scaled; the reference has sqrt(1/d) only)
   lay.young_prio = tun.v[3];
-  FA_DISPATCH(fwd_launch, q, k, v, out, l, m, batch, N, lay, causal, variant, tau, st, tun);
+  return run_scaled([&](const Tun& t, const fa::Layout& L) {
+    return fwd_dispatch_one(q, k, v, out, l, m, batch, N, dp, L, causal, variant, dtype, st, t, tau);
+  }, tun, lay, tau, guard);
 }
 
 int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
                  float* dv, const float* l, const float* m, float* ws, int batch, int N, int d, int dp, fa::Layout lay,
-                 int causal, int variant, int dtype, int stages, hipStream_t st, const Tun& tun = default_tun(), float scale = 0.f) {
+                 int causal, int variant, int dtype, int stages, hipStream_t st, const Tun& tun = default_tun(), float scale = 0.f,
+                 const float* guard = nullptr) {
   const float tau = scale > 0.f ? scale : sqrtf(1.0f / (float)d);
   lay.young_prio = tun.v[3];
-  FA_DISPATCH(bwd_launch, q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, lay, causal, variant, tau, stages, st, tun);
+  return run_scaled([&](const Tun& t, const fa::Layout& L) {
+    return bwd_dispatch_one(q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, dp, L, causal, variant, dtype, stages, st, t, tau);
+  }, tun, lay, tau, guard);
 }
 
 int check_common(int batch, int N, int d, int variant, int dtype) {
@@ -954,7 +1030,7 @@ int fa_mi355x_debug_phase_cycles(unsigned long long* host_out, int n) {
 }
 
 int fa_mi355x_set_tuning(int key, int value) {
-  if (key < 0 || key >= 8) return set_err(FA_ERR_BAD_ARG, "unknown tuning key");
+  if (key < 0 || key >= NTUN) return set_err(FA_ERR_BAD_ARG, "unknown tuning key");
   g_tuning[key] = value;
   return FA_OK;
 }
@@ -1241,6 +1317,70 @@ int fa_mi355x_bwd_dropout(const void* q, const void* k, const void* v, const flo
   if (int rc = set_dropout(lay, rate, scale, seed)) return rc;
   return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
                       causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream);
+}
+
+size_t fa_mi355x_guard_bytes(void) { return (size_t)2 * fa::GUARD_SLOTS * sizeof(float); }
+
+int fa_mi355x_scale_guard(const void* q, const void* k, long rows, int row_elems, int dtype, void* guard, void* stream) {
+  g_err[0] = 0;
+  if (!q || !k || !guard || rows <= 0) return set_err(FA_ERR_BAD_ARG, "bad argument");
+  if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return set_err(FA_ERR_BAD_ARG, "unknown dtype");
+  hipStream_t st = (hipStream_t)stream;
+  // only bf16 rows of 64 / 128 elements ever reach a kernel that folds the scale into an operand: everything else gets an all-zero
+  // guard ("within the budget"; those calls run fp32-scaling kernels whatever it says)
+  if (dtype != FA_DTYPE_BF16 || (row_elems != 64 && row_elems != 128)) {
+    FA_HIP_TRY(hipMemsetAsync(guard, 0, fa_mi355x_guard_bytes(), st));
+    return FA_OK;
+  }
+  const dim3 grid(fa::GUARD_SLOTS, 2);
+  if (row_elems == 64)
+    hipLaunchKernelGGL((fa::scale_guard_kernel<64>), grid, dim3(256), 0, st, (const fa::bf16_t*)q, (const fa::bf16_t*)k, rows, (float*)guard);
+  else
+    hipLaunchKernelGGL((fa::scale_guard_kernel<128>), grid, dim3(256), 0, st, (const fa::bf16_t*)q, (const fa::bf16_t*)k, rows, (float*)guard);
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
+int fa_mi355x_fwd_guarded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H, int N, int d,
+                          int layout, float softmax_scale, int causal, int variant, int dtype, const int* opts, int nopts,
+                          const void* guard, void* stream) {
+  g_err[0] = 0;
+  Tun tun;
+  if (int rc = parse_opts(opts, nopts, tun)) return rc;
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m)) return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if (softmax_scale != 0.f && (!(softmax_scale > 0.f) || !std::isfinite(softmax_scale)))
+    return set_err(FA_ERR_BAD_ARG, "softmax_scale must be positive and finite (0: sqrt(1/d))");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  return fwd_dispatch(q, k, v, out, l, m, B * H, N, d, d, lay, causal ? 1 : 0, variant, dtype, (hipStream_t)stream, tun,
+                      softmax_scale, (const float*)guard);
+}
+
+int fa_mi355x_bwd_guarded(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                          float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int B, int H, int N, int d,
+                          int layout, float softmax_scale, int causal, int variant, int dtype, int stages, const int* opts,
+                          int nopts, const void* guard, void* stream) {
+  g_err[0] = 0;
+  Tun tun;
+  if (int rc = parse_opts(opts, nopts, tun)) return rc;
+  if (stages <= 0 || stages > FA_BWD_STAGE_ALL) return set_err(FA_ERR_BAD_ARG, "bad stages mask");
+  if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
+  if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
+  if (!q || !k || !v || !out || !out_grad || !q_grad || !k_grad || !v_grad || !l || !workspace ||
+      (variant == FA_VARIANT_FA1 && !m))
+    return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
+  if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
+  if (softmax_scale != 0.f && (!(softmax_scale > 0.f) || !std::isfinite(softmax_scale)))
+    return set_err(FA_ERR_BAD_ARG, "softmax_scale must be positive and finite (0: sqrt(1/d))");
+  if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
+  const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
+  return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
+                      causal ? 1 : 0, variant, dtype, stages, (hipStream_t)stream, tun, softmax_scale, (const float*)guard);
 }
 
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d) {

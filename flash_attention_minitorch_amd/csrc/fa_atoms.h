@@ -313,6 +313,13 @@ struct Layout {
   int young_prio;        // slot kernels: waves 4-7 of a workgroup run at s_setprio 1 (0 = off); scheduling only
   int rank_chunk;        // causal slot builds: heads per XCD whose blocks are dispatched together, longest first (map_block_ranked)
   int tiles;             // tiled dK/dV build: consecutive heads per workgroup
+  // Scale guard (round 4; fa_common.h: guard_skip): partial maxima of the squared row norms of q (first GUARD_SLOTS floats) and
+  // k (next GUARD_SLOTS), written by scale_guard_kernel.  A guarded call launches the kernels that carry tau*log2(e) in a bf16
+  // operand with guard_want = 0 and their fp32-scaling twins with guard_want = 1; every workgroup evaluates the same predicate on
+  // entry and the ones of the launch that was not chosen return at once.  nullptr: no guard (the launch always runs).
+  const float* guard;
+  float guard_coef;      // the operand-rounding estimate in units of its budget is guard_coef * sqrt(max |q|^2 * max |k|^2)
+  int guard_want;
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two

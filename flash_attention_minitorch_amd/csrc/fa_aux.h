@@ -40,6 +40,45 @@ __global__ void __launch_bounds__(512) mfma_peak_kernel(float* __restrict__ sink
 }
 
 // ---------------------------------------------------------------------------------------------
+// Scale guard (fa_common.h: guard_skip): the largest squared row norm of q (blockIdx.y = 0) and of k (1), as GUARD_SLOTS partial
+// maxima each.  A row is D contiguous bf16 elements in both layouts ([BH][N][d] and [B][N][H][d]), so the kernel sees `rows` rows of
+// D elements whatever the layout (zero-padded columns add nothing).  HBM-bound: one pass over both tensors, 16 bytes per lane.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256) scale_guard_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, long rows,
+                                                          float* __restrict__ guard) {
+  constexpr int LPR = D / 8;   // lanes per row, 8 elements each
+  static_assert(256 % LPR == 0 && 64 % LPR == 0, "a row's lanes sit in one wave");
+  const bf16_t* p = blockIdx.y ? k : q;
+  const long total = rows * LPR, stride = (long)gridDim.x * 256;
+  float mx = 0.f;
+  constexpr int U = 4;
+  for (long c0 = (long)blockIdx.x * 256 + threadIdx.x; c0 < total; c0 += U * stride) {
+    bf16x8 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long c = c0 + u * stride;
+      f[u] = c < total ? *reinterpret_cast<const bf16x8*>(p + 8 * c) : Atom<bf16_t>::zero();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss = __builtin_fmaf((float)f[u][j], (float)f[u][j], ss);
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+      mx = fmaxf(mx, ss);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) guard[blockIdx.y * GUARD_SLOTS + blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Layout probes (tests only): dump what the atoms read so the lane maps are checked against exact data.
 // 256 threads stage the tile (as the real kernels do); wave 0 runs the probes.
 // ---------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ __global__ void __launch_bounds__(256)
 bwd_prep_kernel(const float* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ l,
                 const float* __restrict__ m, float* __restrict__ nlc, float* __restrict__ ndelta, float* __restrict__ nl2,
                 long rows, int N, Layout lay, int aux_mode, float inv_tau) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   constexpr int LPR = D / 8;  // lanes per row, 8 elements each
   constexpr int RPB = 256 / LPR;
   const int tid = threadIdx.x;
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(NW * 64, MINW)   // MINW: minimum waves per SI
 bwd_dkdv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                 const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dk,
                 float* __restrict__ dv, int N, int nkb, int BH, Layout lay, int causal, float tau, int thin_mode = 0) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   // PAIR (builds for causal launches): one workgroup handles key block p and then key block nkb-1-p (heavy one first): under the causal mask
   // key block kb sweeps nqi - kb*BK/QS query stages, so paired workgroups all do the same work and the grid has no long tail
   // (the launcher sizes the grid with (nkb + 1) / 2 workgroups per batch*head); cf. the paired query blocks of fwd_kernel.
@@ -624,6 +626,7 @@ __global__ void __launch_bounds__(512)
 bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                      const float* __restrict__ nl2, const float* __restrict__ ndelta, float* __restrict__ dk,
                      float* __restrict__ dv, int N, int nkb, int BH, Layout lay, float tau) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
   using A = Atom<T>;
   typedef typename A::frag frag;

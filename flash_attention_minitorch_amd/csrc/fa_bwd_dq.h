@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(64 * NWQ)
 bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
               const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
               int BH, Layout lay, int causal, float tau, int only_qb = -1, DqPrep pa = DqPrep{}) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   constexpr bool CAN_PREP = FEAT == 0 && !CARE;   // the preprocess is folded into the plain main build only (the launcher knows)
   using A = Atom<T>;   // only_qb: as fwd_kernel's
   typedef typename A::frag frag;
@@ -297,6 +298,7 @@ __global__ void __launch_bounds__(512)
 bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dout,
                    const float* __restrict__ nlc, const float* __restrict__ ndelta, float* __restrict__ dq, int N, int nqb,
                    int BH, Layout lay, int causal, float tau, DqPrep pa = DqPrep{}) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   static_assert(D == 64 && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64");
   using A = Atom<T>;
   typedef typename A::frag frag;

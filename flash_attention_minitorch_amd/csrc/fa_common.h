@@ -43,6 +43,28 @@ template <> FA_DEV f32x8 load_frag_buf<float>(rsrc_t rs, int byte_off) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Scale guard.  The MFMA-slot kernels fold c = tau*log2(e) into one bf16 operand (fa_kernels.h, "Scaling"): one more 2^-9 relative
+// rounding of every q_d (k_d), which moves a score (log2 units) by sum_d c q_d k_d eps_d, root-sum-square estimate
+// 2^-9 / sqrt(3) * c * |q| |k|.  scale_guard_kernel reduces the largest squared row norms of q and of k of a call to GUARD_SLOTS
+// partial maxima each; a kernel launched under the guard reads them on entry (two 16-byte loads per lane, L2 hits), and returns at
+// once unless the estimate for the call's largest rows is on its side of the budget (Layout::guard_want: 0 = within, 1 = beyond).
+// Everything is wave-uniform after the reduction; a launch without a guard (Layout::guard == nullptr) pays one scalar branch.
+constexpr int GUARD_SLOTS = 256;
+FA_DEV bool guard_skip(const Layout& L) {
+  if (L.guard == nullptr) return false;
+  const int lane = threadIdx.x & 63;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(L.guard + 4 * lane);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(L.guard + GUARD_SLOTS + 4 * lane);
+  float qm = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), km = fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    qm = fmaxf(qm, __shfl_xor(qm, off));
+    km = fmaxf(km, __shfl_xor(km, off));
+  }
+  const bool beyond = !(L.guard_coef * __builtin_sqrtf(qm * km) <= 1.0f);   // (NaN / Inf inputs count as beyond)
+  return __builtin_amdgcn_readfirstlane((int)beyond) != (L.guard_want != 0);
+}
+
 FA_DEV f32x16 zero16() {
   f32x16 z;
 #pragma unroll

@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
 fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
            float* __restrict__ aux_l, float* __restrict__ aux_m, int N, int nqb, int BH, Layout lay, int causal,
            int aux_mode, float tau, int only_qb = -1) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   // only_qb >= 0: one workgroup per (batch*head) that handles just that 128-query block (the launcher re-runs block 0 behind a
   // slot kernel forced onto a causal launch: the slot kernels have no split-operand path for the rows with few keys)
   using A = Atom<T>;
@@ -385,6 +386,7 @@ template <typename T, int D, bool MASKS = true, int DIAG = 0, int STK = 8192 / D
 __global__ void __launch_bounds__(512, MINW)
 fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, float* __restrict__ o,
                 float* __restrict__ aux_l, int N, int nqb, int BH, Layout lay, int causal, float tau) {
+  if (guard_skip(lay)) return;   // guarded call: this launch is not the chosen one of its pair
   static_assert((D == 64 || D == 128) && sizeof(T) == 2, "slot schedule is laid out for bf16, d = 64 / 128");
   using A = Atom<T>;
   typedef typename A::frag frag;

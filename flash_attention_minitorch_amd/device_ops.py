@@ -44,30 +44,61 @@ def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# per-call kernel options of fa_mi355x_fwd_ex / fa_mi355x_bwd_ex (include/flash_attn_mi355x.h); all give the same results
+# per-call kernel options of fa_mi355x_fwd_ex / _bwd_ex / *_guarded (include/flash_attn_mi355x.h); all give the same results
 OPTS_PHASED = (4, 2, 2)          # the round-1 phased kernels instead of the MFMA-slot ones
-# The MFMA-slot kernels (bf16, d = 64 / 128) fold tau*log2(e) into one bf16 operand (one more 2^-9 relative rounding of q or k, worth
-# 8-10 % of the step); the phased kernels scale every score in fp32.  At the north star's U(-1, 1) inputs both hold 1e-3; for inputs
-# of larger magnitude (scores of tens) the slot kernels' error grows with 2^-9 * sum_d |tau q_d k_d| and this selection keeps the
-# phased kernels' envelope (tests/test_gpu_parity.py::test_large_magnitude_inputs_stay_finite).
-OPTS_EXACT_SCALE = OPTS_PHASED
+# Where the softmax scale is applied (option 8; include/flash_attn_mi355x.h "Softmax scale and the scale guard").  The MFMA-slot
+# kernels (bf16, d = 64 / 128) fold tau*log2(e) into one bf16 operand (one more 2^-9 relative rounding of q or k, worth 8-10 % of the
+# step); every other kernel scales each score in fp32, as the reference does.  The default of this module is the GUARDED call: one
+# device-side pass over q and k (scale_guard, no host synchronisation), then every kernel and its fp32-scaling twin are launched and
+# the one on the wrong side of the budget returns at once.
+OPTS_EXACT_SCALE = (0, 0, 0, 0, 0, 0, 0, 0, 2)    # fp32 scaling whatever the operands look like (no guard pass)
+OPTS_FOLDED_SCALE = (0, 0, 0, 0, 0, 0, 0, 0, 1)   # the caller vouches for U(-1, 1)-sized operands: folded scale, no guard pass
 
 
 def pick_opts(q, k, budget=1e-2):
-    """Which kernels for these operands?  Returns None (the default MFMA-slot kernels) when one more 2^-9 rounding of q / k is
-    estimated to move a score by less than ``budget`` (log2 units; root-sum-square estimate with the largest row norms:
-    2^-9 / sqrt(3) * tau*log2(e) * max_row |q| * max_row |k|), else OPTS_EXACT_SCALE (fp32 scaling).  U(-1, 1) inputs give about 6e-3
-    at d = 64 and 7.5e-3 at d = 128: the north star's domain stays on the fast kernels, inputs 1.3x larger and up go to the phased ones
-    (at x2 the slot kernels' error is twice the phased kernels', profiles/r03_prescale_accuracy.txt).  Costs two reductions and ONE
-    host synchronisation: call it once per tensor family (at model set-up, or every few hundred steps), not per attention call.  A model
-    that folds log2(e)/sqrt(d) into its query projection (softmax_scale = ln 2) never needs it."""
+    """The guard's decision on the HOST (two reductions and ONE synchronisation): OPTS_FOLDED_SCALE when one more 2^-9 rounding of q / k
+    is estimated to move a score by less than ``budget`` (log2 units; 2^-9 / sqrt(3) * tau*log2(e) * max_row |q| * max_row |k|: U(-1, 1)
+    gives about 6e-3 at d = 64 and 7e-3 at d = 128), else OPTS_EXACT_SCALE.  For callers that decide once per tensor family (at model
+    set-up, or every few hundred steps) and then skip the per-call guard pass; the default calls need none of this."""
     if q.dtype != torch.bfloat16 or q.shape[-1] not in (64, 128):
         return None   # fp32 and d = 32 run kernels with fp32 scaling anyway
     d = q.shape[-1]
     qn = q.float().norm(dim=-1).amax()
     kn = k.float().norm(dim=-1).amax()
     est = float(qn * kn) * (1.4426950408889634 / d ** 0.5) * (2.0 ** -9) / 3.0 ** 0.5
-    return OPTS_EXACT_SCALE if est > budget else None
+    return OPTS_EXACT_SCALE if est > budget else OPTS_FOLDED_SCALE
+
+
+def _scale_mode(opts):
+    return int(opts[8]) if opts is not None and len(opts) > 8 else 0
+
+
+def scale_guard(q, k, out=None):
+    """The device-side evidence the folded-scale kernels run on (fa_mi355x_scale_guard): the largest squared row norms of q and k as
+    partial maxima, fa_mi355x_guard_bytes() bytes.  One pass over both tensors, asynchronous, no host synchronisation.  The forward
+    and the backward of one (q, k) pair take the same guard.  Any layout: a row is the last dimension."""
+    if q.dtype != k.dtype or q.shape[-1] != k.shape[-1] or not q.is_cuda or not q.is_contiguous() or not k.is_contiguous():
+        raise ValueError("q and k must be contiguous GPU tensors of one dtype and row length")
+    if out is None:
+        out = torch.empty(_lib.core().fa_mi355x_guard_bytes() // 4, dtype=torch.float32, device=q.device)
+    d = q.shape[-1]
+    if q.numel() != k.numel():
+        raise ValueError("q and k must have the same number of rows")
+    _lib.check(_lib.core().fa_mi355x_scale_guard(_ptr(q), _ptr(k), q.numel() // d, d, _DTYPES[q.dtype], _ptr(out), _stream_ptr()))
+    return out
+
+
+def _auto_guard(q, k, opts, guard):
+    """guard = "auto" (the default): a guard pass where a folded-scale kernel could run (bf16, d = 64 / 128, option 8 left at 0)."""
+    if not isinstance(guard, str):
+        return guard
+    if _lib.DIAG:
+        return None   # (tools/ on the diagnostic library: its process-wide default is the folded scale, option 8 = 1)
+    if q.dtype != torch.bfloat16 or q.shape[-1] not in (64, 128) or _scale_mode(opts) != 0:
+        return None
+    return scale_guard(q, k)
+
+
 OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # DIAGNOSTIC LIBRARY ONLY (tools/check_fused.py): dQ inside the key-stationary kernel, ordered hand-off
 # DIAGNOSTIC LIBRARY ONLY (tools/check_chain.py): the chained one-pass backward (bf16, d = 64, non-causal, N % 256 == 0): five products
 # instead of seven, the running dQ tiles carried through memory along a workgroup's key blocks, fp32 atomics only from each chain's last
@@ -89,9 +120,10 @@ def _pad_cols(t, dp):
     return torch.nn.functional.pad(t, (0, dp - t.shape[-1]))
 
 
-def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None):
+def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None, guard="auto"):
     """Forward.  Returns (out fp32, l, m): FA-1 -> l = sum exp(s - rowmax), m = rowmax;
-    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*).
+    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*).  ``guard``: "auto" = run the scale-guard pass
+    for this call (scale_guard), a tensor = the guard of this (q, k) pair computed before, None = none (fp32 scaling).
     Any head dim d <= 128: d outside {32, 64, 128} is zero-padded to the next of them on the device (tau keeps the caller's d; the
     reference operator takes any d up to its assert, minitorch/cuda_kernel_ops.py:527-581 / src/flash_attn_fw.cu:43)."""
     bh, n, d = _check_inputs(q, k, v)
@@ -118,8 +150,10 @@ def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None,
     if variant == _lib.FA_VARIANT_FA1 and m is None:
         m = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
     arr, cnt = _lib.opts_array(opts)
-    _lib.check(_lib.core().fa_mi355x_fwd_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), bh, n, d,
-                                            int(bool(causal)), variant, _DTYPES[q.dtype], arr, cnt, _stream_ptr()))
+    guard = _auto_guard(q, k, opts, guard)
+    _lib.check(_lib.core().fa_mi355x_fwd_guarded(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), bh, 1, n, d,
+                                                 _lib.FA_LAYOUT_BHND, 0.0, int(bool(causal)), variant, _DTYPES[q.dtype], arr, cnt,
+                                                 _ptr(guard), _stream_ptr()))
     return out, l, m
 
 
@@ -152,9 +186,10 @@ STAGE_PREP, STAGE_DKDV, STAGE_DQ, STAGE_ALL = 1, 2, 4, 7
 
 
 def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2,
-                   workspace=None, grads=None, stages=STAGE_ALL, opts=None):
+                   workspace=None, grads=None, stages=STAGE_ALL, opts=None, guard="auto"):
     """Backward.  out: the forward's fp32 output.  Returns (dq, dk, dv) fp32.
-    ``stages`` restricts the call to some of its kernels (profiling only); ``opts``: per-call kernel options (see OPTS_*)."""
+    ``stages`` restricts the call to some of its kernels (profiling only); ``opts``: per-call kernel options (see OPTS_*);
+    ``guard`` as flash_attn_fwd (pass the forward's guard tensor to save the second pass over q and k)."""
     bh, n, d = _check_inputs(q, k, v, out_grad)
     if out.dtype != torch.float32 or out.shape != q.shape or not out.is_contiguous():
         raise ValueError("out must be the forward's contiguous float32 output")
@@ -179,14 +214,15 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
         grads = tuple(torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
     dq, dk, dv = grads
     arr, cnt = _lib.opts_array(opts)
-    _lib.check(_lib.core().fa_mi355x_bwd_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
-                                            _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(workspace), bh, n, d,
-                                            int(bool(causal)), variant, _DTYPES[q.dtype], int(stages), arr, cnt,
-                                            _stream_ptr()))
+    guard = _auto_guard(q, k, opts, guard)
+    _lib.check(_lib.core().fa_mi355x_bwd_guarded(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
+                                                 _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(workspace), bh, 1, n, d,
+                                                 _lib.FA_LAYOUT_BHND, 0.0, int(bool(causal)), variant, _DTYPES[q.dtype], int(stages),
+                                                 arr, cnt, _ptr(guard), _stream_ptr()))
     return dq, dk, dv
 
 
-def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None):
+def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None, guard="auto", opts=None):
     """Forward on (B, N, H, d) tensors -- the layout minitorch's projection writes before its
     permute(0,2,1,3).contiguous() (minitorch/modules_transfomer.py:67-89): no head-split copies.
     Returns (out (B, N, H, d) fp32, l (B, H, N), m (B, H, N) or None).
@@ -201,32 +237,26 @@ def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, soft
     out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     l = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
     m = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if variant == _lib.FA_VARIANT_FA1 else None
-    if softmax_scale is not None:
-        _lib.check(_lib.core().fa_mi355x_fwd_scaled(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
-                                                    _lib.FA_LAYOUT_BNHD, float(softmax_scale), int(bool(causal)), variant,
-                                                    _DTYPES[q.dtype], _stream_ptr()))
-        return out, l, m
-    _lib.check(_lib.core().fa_mi355x_fwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
-                                                _lib.FA_LAYOUT_BNHD, int(bool(causal)), variant, _DTYPES[q.dtype],
-                                                _stream_ptr()))
+    arr, cnt = _lib.opts_array(opts)
+    guard = _auto_guard(q, k, opts, guard)   # (with softmax_scale = ln 2 the library ignores it: the folded factor is 1)
+    _lib.check(_lib.core().fa_mi355x_fwd_guarded(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
+                                                 _lib.FA_LAYOUT_BNHD, float(softmax_scale or 0.0), int(bool(causal)), variant,
+                                                 _DTYPES[q.dtype], arr, cnt, _ptr(guard), _stream_ptr()))
     return out, l, m
 
 
-def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None):
+def flash_attn_bwd_bnhd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None,
+                        guard="auto", opts=None):
     """Backward on (B, N, H, d) tensors; returns (dq, dk, dv) in the same layout, fp32 (``softmax_scale`` as the forward's)."""
     B, N, H, d = q.shape
     ws = _workspace(B * H, N, d, q.device)
     dq, dk, dv = (torch.empty(q.shape, dtype=torch.float32, device=q.device) for _ in range(3))
-    if softmax_scale is not None:
-        _lib.check(_lib.core().fa_mi355x_bwd_scaled(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
-                                                    _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d, _lib.FA_LAYOUT_BNHD,
-                                                    float(softmax_scale), int(bool(causal)), variant, _DTYPES[q.dtype],
-                                                    _stream_ptr()))
-        return dq, dk, dv
-    _lib.check(_lib.core().fa_mi355x_bwd_layout(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq),
-                                                _ptr(dk), _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d,
-                                                _lib.FA_LAYOUT_BNHD, int(bool(causal)), variant, _DTYPES[q.dtype],
-                                                _stream_ptr()))
+    arr, cnt = _lib.opts_array(opts)
+    guard = _auto_guard(q, k, opts, guard)
+    _lib.check(_lib.core().fa_mi355x_bwd_guarded(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(out_grad), _ptr(dq), _ptr(dk),
+                                                 _ptr(dv), _ptr(l), _ptr(m), _ptr(ws), B, H, N, d, _lib.FA_LAYOUT_BNHD,
+                                                 float(softmax_scale or 0.0), int(bool(causal)), variant, _DTYPES[q.dtype],
+                                                 STAGE_ALL, arr, cnt, _ptr(guard), _stream_ptr()))
     return dq, dk, dv
 
 
@@ -307,16 +337,18 @@ class _FlashAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, causal, variant):
-        o, l, m = flash_attn_fwd(q, k, v, causal, variant)
-        ctx.save_for_backward(q, k, v, o, l, m if m is not None else torch.empty(0, device=q.device))
+        guard = _auto_guard(q, k, None, "auto") if q.shape[-1] in _NATIVE_D else None   # ONE pass over q, k for forward and backward
+        o, l, m = flash_attn_fwd(q, k, v, causal, variant, guard=guard)
+        none = torch.empty(0, device=q.device)
+        ctx.save_for_backward(q, k, v, o, l, m if m is not None else none, guard if guard is not None else none)
         ctx.causal, ctx.variant = causal, variant
         return o
 
     @staticmethod
     def backward(ctx, out_grad):
-        q, k, v, o, l, m = ctx.saved_tensors
+        q, k, v, o, l, m, guard = ctx.saved_tensors
         dq, dk, dv = flash_attn_bwd(q, k, v, o, out_grad.to(q.dtype).contiguous(), l,
-                                    m if m.numel() else None, ctx.causal, ctx.variant)
+                                    m if m.numel() else None, ctx.causal, ctx.variant, guard=guard if guard.numel() else None)
         return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None
 
 

@@ -27,16 +27,20 @@ class _FlashAttnBNHD(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, causal, softmax_scale=None):
-        o, l, _ = device_ops.flash_attn_fwd_bnhd(q, k, v, causal, _lib.FA_VARIANT_FA2, softmax_scale)
-        ctx.save_for_backward(q, k, v, o, l)
+        # one scale-guard pass over q, k serves the forward and the backward (none needed when the caller folded the scale: the
+        # kernels' factor is then exactly 1)
+        guard = None if softmax_scale is not None else device_ops._auto_guard(q, k, None, "auto")
+        o, l, _ = device_ops.flash_attn_fwd_bnhd(q, k, v, causal, _lib.FA_VARIANT_FA2, softmax_scale, guard=guard)
+        none = torch.empty(0, device=q.device)
+        ctx.save_for_backward(q, k, v, o, l, guard if guard is not None else none)
         ctx.causal, ctx.softmax_scale = causal, softmax_scale
         return o
 
     @staticmethod
     def backward(ctx, out_grad):
-        q, k, v, o, l = ctx.saved_tensors
+        q, k, v, o, l, guard = ctx.saved_tensors
         dq, dk, dv = device_ops.flash_attn_bwd_bnhd(q, k, v, o, out_grad.to(q.dtype).contiguous(), l, None, ctx.causal,
-                                                    _lib.FA_VARIANT_FA2, ctx.softmax_scale)
+                                                    _lib.FA_VARIANT_FA2, ctx.softmax_scale, guard=guard if guard.numel() else None)
         return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None
 
 
@@ -45,16 +49,18 @@ class _FlashAttnBHND(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, causal):
-        o, l, _ = device_ops.flash_attn_fwd(q, k, v, causal, _lib.FA_VARIANT_FA2)
-        ctx.save_for_backward(q, k, v, o, l)
+        guard = device_ops._auto_guard(q, k, None, "auto")
+        o, l, _ = device_ops.flash_attn_fwd(q, k, v, causal, _lib.FA_VARIANT_FA2, guard=guard)
+        none = torch.empty(0, device=q.device)
+        ctx.save_for_backward(q, k, v, o, l, guard if guard is not None else none)
         ctx.causal = causal
         return o
 
     @staticmethod
     def backward(ctx, out_grad):
-        q, k, v, o, l = ctx.saved_tensors
+        q, k, v, o, l, guard = ctx.saved_tensors
         dq, dk, dv = device_ops.flash_attn_bwd(q, k, v, o, out_grad.to(q.dtype).contiguous(), l, None, ctx.causal,
-                                               _lib.FA_VARIANT_FA2)
+                                               _lib.FA_VARIANT_FA2, guard=guard if guard.numel() else None)
         return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None
 
 

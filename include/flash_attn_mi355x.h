@@ -59,10 +59,14 @@ void launch_flash_attn_bw(float* q, float* k, float* v, float* out, float* out_g
 #define FA_DTYPE_F32  0         /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
 #define FA_DTYPE_BF16 1         /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate / softmax state */
 
+/* Tensor layouts of the *_layout / *_scaled / *_guarded / *_masked / *_dropout entry points (see fa_mi355x_fwd_layout). */
+#define FA_LAYOUT_BHND 0        /* [B][H][N][d]: the reference's contiguous (batch*head, N, d) */
+#define FA_LAYOUT_BNHD 1        /* [B][N][H][d]: what minitorch's projection writes before its permute + contiguous */
+
 /* Status codes of the int-returning entry points. */
 #define FA_OK 0
 #define FA_ERR_BAD_ARG 1        /* null pointer, non-positive size, unknown variant/dtype */
-#define FA_ERR_UNSUPPORTED_D 2  /* device path needs d in {32, 64, 128}; the host path pads any d <= 128 */
+#define FA_ERR_UNSUPPORTED_D 2  /* row length not in {32, 64, 128}: other d <= 128 go through fa_mi355x_*_padded (device) or the host launchers */
 #define FA_ERR_HIP 3            /* a HIP call failed: see fa_mi355x_last_error() */
 
 /* Host-pointer launchers behind the six shims (same argument meaning as the reference FFI + variant). */
@@ -77,9 +81,9 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m,
                   int batch, int N, int d, int causal, int variant, int dtype, void* stream);
 
-/* Bytes of scratch fa_mi355x_bwd needs: 3 * batch * N floats (-L/tau, -rowsum(dO*O), -L*log2(e)) and, for shapes the one-pass
- * backward takes (d = 64, N a multiple of 256), its flags and running dQ tiles (at most 32 MiB + 16.25 KiB).  Every
- * backward entry point below expects a workspace of at least this size. */
+/* Bytes of scratch fa_mi355x_bwd needs: 3 * batch * N floats (-L/tau, -rowsum(dO*O), -L*log2(e)).  Every backward entry point
+ * below expects a workspace of at least this size.  (The diagnostic library adds the hand-off region of its round-2 one-pass
+ * backward for d = 64, N a multiple of 256; the product library has no kernel that needs more.) */
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
 
 /* The same for a backward call with per-call options (fa_mi355x_bwd_ex).  Product library: fa_mi355x_bwd_workspace_bytes.  Diagnostic
@@ -88,11 +92,9 @@ size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
  * batch * nchains >= CUs (256 MiB at batch 64, N 4096 on 256 CUs). */
 size_t fa_mi355x_bwd_workspace_bytes_ex(int batch, int N, int d, const int* opts, int nopts);
 
-/* Synchronous check of the one-pass backward's error word in a workspace the last backward call used: *status = 0 if no
- * hand-off wait timed out (always 0 for shapes / calls that ran the two-kernel backward).  Returns FA_ERR_HIP and a
- * message when it is non-zero (the gradients of that call are then invalid).  The one-pass kernel is a persistent grid
- * whose workgroups wait for each other: do not run two backward calls of such shapes concurrently on different streams
- * of one device. */
+/* Product library: a no-op that sets *status = 0 (no kernel of it waits for another workgroup, and backward calls may run
+ * concurrently on different streams).  Diagnostic library: the error word of the round-2 one-pass backward (a persistent grid with a
+ * bounded-spin hand-off, opts[4] = 2) in a workspace the last backward call used; FA_ERR_HIP and a message when a wait timed out. */
 int fa_mi355x_bwd_status(const void* workspace, int batch, int N, int d, int* status);
 
 /* Backward on device pointers.  out: float (the forward's output); out_grad: dtype elements;
@@ -115,7 +117,7 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
                          void* workspace, int batch, int N, int d, int causal, int variant, int dtype, int stages,
                          void* stream);
 
-/* Forward / backward with per-call kernel options (no process-wide state): opts[0..nopts-1], nopts <= 8, 0 = default.
+/* Forward / backward with per-call kernel options (no process-wide state): opts[0..nopts-1], nopts <= 10, 0 = default.
  *   opts[0]  dK/dV kernel: 3 = (d = 64) the phased kernel with the slot path on unmasked stages (what causal launches that do not
  *            fill the chip run anyway); 4 = the compiler-interleaved phased kernel (fp32 scaling: OPTS_EXACT_SCALE); 5 = at d = 64, causal,
  *            N % 256 == 0: the causal build of the continuous slot pipeline whatever the launch size
@@ -137,6 +139,12 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *            kernels) and head-by-head order for the unpaired dK/dV launches (fp32 d = 64, bf16 d = 128); 2 = one block per
  *            workgroup dispatched longest first across a chunk of heads, everywhere; 0 = per kernel what measured faster (slot
  *            builds: ranked below 8 rounds of the chip; phased forward / dQ: paired; unpaired dK/dV: ranked)
+ *   opts[8]  where the softmax scale is applied (bf16, d = 64 / 128; "Softmax scale and the scale guard" below): 0 = fp32 scaling of
+ *            every score, as the reference does, unless the call carries a scale guard (fa_mi355x_*_guarded); 1 = the caller vouches
+ *            that q and k are of the north star's U(-1, 1) magnitude: the MFMA-slot kernels that fold tau*log2(e) into a bf16
+ *            operand run unguarded (8-10 % faster; at x2 inputs their error on O doubles to 1.4e-3); 2 = fp32 scaling whatever a
+ *            guard says; 3 = fa_mi355x_plan only: plan a guarded call (both launches of every pair)
+ *   opts[9]  unused
  * Values that lost their A/B (opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1, opts[4] = 2 / 3 = the one-pass
  * backwards, opts[6] = 1) exist in the diagnostic library only; the product library answers them with FA_ERR_BAD_ARG.
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this
@@ -146,6 +154,31 @@ int fa_mi355x_fwd_ex(const void* q, const void* k, const void* v, float* out, fl
 int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
                      float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int batch, int N, int d,
                      int causal, int variant, int dtype, int stages, const int* opts, int nopts, void* stream);
+
+/* ---- Softmax scale and the scale guard (round 4) ----
+ * The reference multiplies every score by tau = sqrt(1/d) in fp32 (src/flash_attn2_fw.cu:152-167).  The fastest bf16 kernels here
+ * (MFMA-slot pipelines, d = 64 / 128) instead carry tau*log2(e) inside one bf16 MFMA operand, re-rounded once: exp2 then needs no
+ * multiply per score (8-10 % of the step), at the price of one more 2^-9 relative rounding of q (or k).  That is invisible for inputs of
+ * the reference tests' U(-1, 1) magnitude and grows with the square of the input magnitude, so those kernels run only on evidence:
+ *   fa_mi355x_scale_guard   one pass over q and k (HBM-bound: 13 us at B=8, H=8, N=4096, d=64): the largest squared row norms, as
+ *                           fa_mi355x_guard_bytes() bytes of device memory; rows = the number of rows of row_elems contiguous
+ *                           elements (B*H*N rows of d in either layout; padded rows: dp).  fp32 or other row lengths: zero-filled.
+ *   fa_mi355x_*_guarded     launch the selected kernels AND their fp32-scaling twins; every workgroup evaluates the guard on entry
+ *                           (estimate 2^-9/sqrt(3) * tau*log2(e) * max|q| * max|k| against a budget of 1e-2 in log2 units: U(-1, 1)
+ *                           gives 5.7e-3 at d = 64, inputs 1.3x larger and up take fp32 scaling) and the launch on the wrong side
+ *                           returns at once: no host synchronisation, about 4 us per skipped launch.  guard = NULL, or any other
+ *                           entry point of this header: fp32 scaling (opts[8] = 1 overrides).  The forward and the backward of one
+ *                           q / k pair take the same guard (compute it once).  softmax_scale = 0: sqrt(1/d).
+ * A caller that folds log2(e)/sqrt(d) into its query projection and passes softmax_scale = ln(2) needs no guard: the factor is 1. */
+size_t fa_mi355x_guard_bytes(void);
+int fa_mi355x_scale_guard(const void* q, const void* k, long rows, int row_elems, int dtype, void* guard, void* stream);
+int fa_mi355x_fwd_guarded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H, int N, int d,
+                          int layout, float softmax_scale, int causal, int variant, int dtype, const int* opts, int nopts,
+                          const void* guard, void* stream);
+int fa_mi355x_bwd_guarded(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
+                          float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int B, int H, int N, int d,
+                          int layout, float softmax_scale, int causal, int variant, int dtype, int stages, const int* opts,
+                          int nopts, const void* guard, void* stream);
 
 /* The same two operations with the caller's softmax scale instead of sqrt(1/d): P = softmax_k(softmax_scale * q.k).  The reference's
  * operator has no such argument (tau = sqrt(1/d) is fixed, src/flash_attn_fw.cu:37); it is here for callers that fold the scale into
@@ -182,8 +215,6 @@ int fa_mi355x_plan(int batch, int N, int d, int causal, int variant, int dtype, 
  * inverse for the output (minitorch/modules_transfomer.py:67-89,137-139): four full-tensor copies per layer.
  * FA_LAYOUT_BNHD reads and writes [B][N][H][d] directly (element (b,n,h,:) at ((b*N + n)*H + h)*d);
  * l, m and the workspace stay [B][H][N]. */
-#define FA_LAYOUT_BHND 0
-#define FA_LAYOUT_BNHD 1
 int fa_mi355x_fwd_layout(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H,
                          int N, int d, int layout, int causal, int variant, int dtype, void* stream);
 int fa_mi355x_bwd_layout(const void* q, const void* k, const void* v, const float* out, const void* out_grad,

@@ -300,10 +300,14 @@ def test_slot_kernels_block_and_ring_boundaries(dev, N, causal):
             for nm, got in zip(("o", "L", "dq", "dk", "dv"), outs[tag]):
                 assert np.all(np.isfinite(got)), (tag, nm)
                 assert maxabs(got, ref[nm]) < tol, (tag, nm, maxabs(got, ref[nm]))
-    # different tiling of the key loop and (round 3) tau*log2(e) folded into the slot kernels' bf16 operand instead of an fp32 fma
-    # per score: both are within tol of the oracle, so within tol of each other (a tiling bug would be orders of magnitude off)
+    # Same arithmetic per element, different tiling of the key loop: the two builds agree far inside the tolerance (0.5 * tol) --
+    # except where the slot build carries tau*log2(e) in its bf16 operand instead of an fp32 fma per score (round 3): the mask-free
+    # forward / dQ builds (N a multiple of 128 without the mask, of 256 with it) and the dK/dV slot kernel always.  There both are
+    # within tol of the oracle and within tol of each other (a tiling bug would be orders of magnitude off).
+    folded = N % 256 == 0 or (not causal and N % 128 == 0)
     for nm, a, b in zip(("o", "L", "dq", "dk", "dv"), outs["slot"], outs["phased"]):
-        assert maxabs(a, b) < tol, (nm, maxabs(a, b))
+        lim = tol if (folded or nm in ("dk", "dv")) else 0.5 * tol
+        assert maxabs(a, b) < lim, (nm, maxabs(a, b))
 
 
 @pytest.mark.parametrize("dtype,d", [("bf16", 64), ("bf16", 128), ("f32", 32), ("f32", 64)])
@@ -487,14 +491,71 @@ def test_every_accepted_option_value_against_the_oracle(dev, opts, causal):
         assert maxabs(to_np(got)[heads], ref[nm]) < TOLBF, (opts, nm, maxabs(to_np(got)[heads], ref[nm]))
 
 
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_scale_guard_routes_by_operand_size_without_a_host_sync(dev, causal, d):
+    """Round 4 (VERDICT r3 missing 3): the default call is safe outside U(-1, 1).  device_ops issues GUARDED calls: one
+    device-side pass over q and k (fa_mi355x_scale_guard), then every kernel that folds tau*log2(e) into a bf16 operand is launched
+    beside its fp32-scaling twin and the workgroups of the wrong side return at once.  Checked by bitwise identity: at U(-1, 1) the
+    default equals the explicitly folded call (option 8 = 1), at x2 and x6 it equals the explicit fp32-scaling call (option 8 = 2),
+    whose x2 results meet 1e-3 * scale where the folded kernels do not (profiles/r03_prescale_accuracy.txt); the decision is the
+    host formula's (pick_opts), taken on the device; the plain C entry points (no guard) scale in fp32."""
+    import ctypes
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    rng = np.random.default_rng(8800 + d)
+    BH, N = 4, 512
+    for amp in (1.0, 1.25, 2.0, 6.0):
+        arrs = [oracle.bf16_round(amp * rand_u(rng, (BH, N, d))) for _ in range(3)] + [oracle.bf16_round(rand_u(rng, (BH, N, d)))]
+        t = [torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs]
+        guard = dev.scale_guard(t[0], t[1])
+        gq, gk = float(guard[:256].max()), float(guard[256:].max())
+        assert abs(gq - float(t[0].float().pow(2).sum(-1).max())) < 1e-3 * gq and abs(gk - float(t[1].float().pow(2).sum(-1).max())) < 1e-3 * gk
+        want_exact = dev.pick_opts(t[0], t[1]) == dev.OPTS_EXACT_SCALE
+        assert want_exact == (amp >= 2.0) or amp == 1.25   # (1.25: folded at d = 64, fp32 scaling at d = 128, where U(-1, 1) sits at 0.7 of the budget)
+
+        def run(opts, guard_arg):
+            o, L, _ = dev.flash_attn_fwd(*t[:3], causal, opts=opts, guard=guard_arg)
+            g = dev.flash_attn_bwd(*t[:3], o, t[3], L, None, causal, opts=opts, guard=guard_arg)
+            return [to_np(x) for x in (o, L) + tuple(g)]
+
+        default = run(None, "auto")
+        shared = run(None, guard)                       # one guard pass for forward and backward
+        folded = run(dev.OPTS_FOLDED_SCALE, None)
+        exact = run(dev.OPTS_EXACT_SCALE, None)
+        same = exact if want_exact else folded
+        for a, b, c in zip(default, shared, same):
+            assert np.array_equal(a, b) and np.array_equal(a, c), (amp, maxabs(a, c))
+        bf = _lib.FA_DTYPE_BF16
+        differ = _lib.plan(BH, N, d, causal, 2, bf, 0, dev.OPTS_FOLDED_SCALE) != _lib.plan(BH, N, d, causal, 2, bf, 0, dev.OPTS_EXACT_SCALE)
+        if differ:
+            assert not np.array_equal(folded[0], exact[0])   # (they ARE different kernels; a causal launch this small runs the phased ones anyway)
+        # the plain C entry point carries no guard: fp32 scaling
+        o2 = torch.empty((BH, N, d), dtype=torch.float32, device="cuda")
+        l2 = torch.empty((BH, N), dtype=torch.float32, device="cuda")
+        vp = lambda x: ctypes.c_void_p(x.data_ptr())
+        _lib.check(_lib.core().fa_mi355x_fwd(vp(t[0]), vp(t[1]), vp(t[2]), vp(o2), vp(l2), None, BH, N, d, int(causal), 2, 1, None))
+        assert np.array_equal(to_np(o2), exact[0]) and np.array_equal(to_np(l2), exact[1])
+        if amp == 2.0:   # the point of it: at x2 the default now has the fp32-scaling kernels' error (5e-3 * scale at this short N,
+            # where the bf16 rounding of P is averaged over 512 keys only), and on L, which sums every key of a row, it is well below
+            # the folded kernels' (2.9e-3 against 1e-6 at the metric shape, profiles/r03_prescale_accuracy.txt)
+            ref = oracle_heads(*arrs, causal, range(BH))
+            for nm, got in zip(("o", "L", "dq", "dk", "dv"), default):
+                scale = max(1.0, float(np.max(np.abs(ref[nm]))))
+                assert maxabs(got, ref[nm]) < 5e-3 * scale, (nm, maxabs(got, ref[nm]), scale)
+            if differ:
+                assert maxabs(default[1], ref["L"]) < 0.5 * maxabs(folded[1], ref["L"])
+
+
 def test_pick_opts_keeps_the_north_star_domain_on_the_fast_kernels(dev):
-    """device_ops.pick_opts: U(-1, 1) operands stay on the default MFMA-slot kernels, operands a few times larger are sent to the kernels
-    with fp32 scaling, and with that choice the x6 inputs of test_large_magnitude_inputs_stay_finite meet the 5e-3 bound."""
+    """device_ops.pick_opts (the scale guard's decision taken on the host, once per tensor family): U(-1, 1) operands may run the
+    folded-scale MFMA-slot kernels unguarded, operands a few times larger are sent to the kernels with fp32 scaling, and with that
+    choice the x6 inputs of test_large_magnitude_inputs_stay_finite meet the 5e-3 bound."""
     import torch
     rng = np.random.default_rng(61)
     BH, N, d = 4, 512, 64
     mk = lambda s: torch.from_numpy(oracle.bf16_round(s * rand_u(rng, (BH, N, d)))).to("cuda", torch.bfloat16)
-    assert dev.pick_opts(mk(1.0), mk(1.0)) is None
+    assert dev.pick_opts(mk(1.0), mk(1.0)) == dev.OPTS_FOLDED_SCALE
     assert dev.pick_opts(mk(1.0).float(), mk(1.0).float()) is None and dev.pick_opts(mk(6.0), mk(6.0)) == dev.OPTS_EXACT_SCALE
     assert dev.pick_opts(mk(2.0), mk(2.0)) == dev.OPTS_EXACT_SCALE
     arrs = [oracle.bf16_round(6.0 * rand_u(rng, (BH, N, d))) for _ in range(3)] + [oracle.bf16_round(rand_u(rng, (BH, N, d)))]
@@ -783,8 +844,9 @@ def test_large_magnitude_inputs_stay_finite(dev, causal, d):
     kernels move their reference on most rows (P = exp2(c*s - c*m_ref) is computed BEFORE the guard is checked); the slot kernels'
     reference-free sweep (round 3) over- or underflows on many rows and their waves take the cold path (fwd_redo_rows).  The
     softmax is nearly one-hot here, so the bf16 bound is taken relative to the output scale.
-    Accuracy envelope: the kernels with fp32 scaling (OPTS_EXACT_SCALE: the phased kernels) keep 5e-3 * scale; the slot kernels, which
-    carry tau*log2(e) in a bf16 operand, must stay finite and inside operand_rounding_envelope (about 0.1 * scale at these scores)."""
+    Accuracy envelope: the kernels with fp32 scaling (OPTS_EXACT_SCALE, and since round 4 the DEFAULT call, whose scale guard routes
+    operands of this size to them) keep 5e-3 * scale; the slot kernels, which carry tau*log2(e) in a bf16 operand and run here only
+    because option 8 = 1 vouches for the operands, must stay finite and inside operand_rounding_envelope (about 0.1 * scale)."""
     import torch
     rng = np.random.default_rng(77)
     BH, N = 2, 512
@@ -794,9 +856,11 @@ def test_large_magnitude_inputs_stay_finite(dev, causal, d):
     arrs = [oracle.bf16_round(amp * rand_u(rng, (BH, N, d))) for _ in range(3)] + [oracle.bf16_round(rand_u(rng, (BH, N, d)))]
     tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs)
     ref = oracle_heads(*arrs, causal, range(BH))
-    slot = (5 if causal else 0, 3, 3)   # the slot kernels whatever the launch size (causal: their causal builds)
+    # the slot kernels whatever the launch size (causal: their causal builds) AND whatever the operands (option 8 = 1: no guard)
+    slot = (5 if causal else 0, 3, 3, 0, 0, 0, 0, 0, 1)
     env = operand_rounding_envelope(arrs[0], arrs[1])
-    for opts, rel in ((dev.OPTS_EXACT_SCALE, 5e-3), (None, env), (slot, env)):
+    # round 4: the DEFAULT call runs under the scale guard, which sends these operands to the fp32-scaling kernels: 5e-3 * scale again
+    for opts, rel in ((dev.OPTS_EXACT_SCALE, 5e-3), (None, 5e-3), (slot, env)):
         o, L, _ = dev.flash_attn_fwd(tq, tk, tv, causal, opts=opts)
         dq, dk, dv = dev.flash_attn_bwd(tq, tk, tv, o, tdo, L, None, causal, opts=opts)
         for nm, got in (("o", o), ("L", L), ("dq", dq), ("dk", dk), ("dv", dv)):
@@ -932,9 +996,9 @@ def test_online_softmax_rescale_branch_is_exercised(dev):
     env = operand_rounding_envelope(arrs[0], arrs[1])
     for causal in (False, True):
         for tdt, tol in ((torch.bfloat16, TOLBF), (torch.float32, TOL32)):
-            # (0, 3, 3): the slot kernels whatever the launch size (causal, N = 512: the diagonal-block phase moves the reference);
+            # (0, 3, 3, .., 1): the slot kernels whatever the launch size and the operands (causal, N = 512: the diagonal-block phase moves the reference);
             # OPTS_EXACT_SCALE: the phased kernels, whose forward moves its reference at the spiked tiles
-            for opts in ((None, (5 if causal else 0, 3, 3), dev.OPTS_EXACT_SCALE) if tdt == torch.bfloat16 else (None,)):
+            for opts in ((None, (5 if causal else 0, 3, 3, 0, 0, 0, 0, 0, 1), dev.OPTS_EXACT_SCALE) if tdt == torch.bfloat16 else (None,)):
                 t = [torch.from_numpy(a).to("cuda", tdt) for a in arrs]
                 o, L, _ = dev.flash_attn_fwd(*t[:3], causal=causal, opts=opts)
                 dq, dk, dv = dev.flash_attn_bwd(*t[:3], o, t[3], L, causal=causal, opts=opts)
@@ -945,7 +1009,7 @@ def test_online_softmax_rescale_branch_is_exercised(dev):
                     # (the spiked rows put nearly all their weight on ONE key, so bf16 P / dS are not averaged: 5e-3)
                     # (the slot kernels carry tau*log2(e) in a bf16 operand: scores of ~45 on the spiked keys: operand_rounding_envelope)
                     scale = max(1.0, float(np.max(np.abs(ref[nm]))))
-                    exact = tdt != torch.bfloat16 or opts == dev.OPTS_EXACT_SCALE
+                    exact = tdt != torch.bfloat16 or opts is None or opts == dev.OPTS_EXACT_SCALE   # (None: the guard sees |k| ~ 12 |q|)
                     lim = ((5e-3 if exact else env) if tdt == torch.bfloat16 else tol) * scale
                     assert maxabs(to_np(got), ref[nm]) < lim, (causal, tdt, opts, nm, maxabs(to_np(got), ref[nm]), scale)
 

@@ -28,14 +28,28 @@ def test_plan_matches_what_bench_times(shape, fwd_names, bwd_names):
     assert torch.cuda.is_available()
     BH, N, d, causal, dtype = shape
     dt = _lib.FA_DTYPE_BF16 if dtype == "bf16" else _lib.FA_DTYPE_F32
-    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0) == fwd_names
-    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_ALL) == bwd_names
-    stages, k_fwd, k_dq, k_dkdv = bench.stage_plan(device_ops, BH, N, d, causal, dtype, None, lambda: None, lambda s=7: None)
-    assert [n for n, _ in stages] == fwd_names + bwd_names   # no preprocess kernel: the dQ launch does it and runs first
+    fold = device_ops.OPTS_FOLDED_SCALE   # the kernels a call runs once the operands are vouched for (option 8 = 1) or inside the guard's budget
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0, fold) == fwd_names
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_ALL, fold) == bwd_names
+    # round 4: WITHOUT evidence about the operands a call scales every score in fp32, as the reference does (the phased kernels) ...
+    exact_fwd = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0)
+    assert exact_fwd[0] == "fwd_kernel" and exact_fwd == _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0, device_ops.OPTS_EXACT_SCALE)
+    # ... and a GUARDED call (what device_ops and bench.py issue by default) launches both sides of every pair
+    assert bench.guarded_call(BH, N, d, causal, dtype, None)
+    guarded = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0, bench.with_scale_mode(None, 3))
+    assert guarded == fwd_names + exact_fwd
+    gb = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_ALL, bench.with_scale_mode(None, 3))
+    if d == 64:     # (d = 128: the backward kernels scale in fp32 anyway: one launch each)
+        assert gb[:2] == bwd_names and set(gb[2:]) == {"bwd_dq_kernel", "bwd_dkdv_kernel"}
+    else:
+        assert gb == bwd_names
+    stages, k_fwd, k_dq, k_dkdv = bench.stage_plan(device_ops, BH, N, d, causal, dtype, None, lambda: None, lambda s=7: None, lambda: None)
+    # the guard pass first; no preprocess kernel: the dQ launch does it and runs before dK/dV
+    assert [n for n, _ in stages] == ["scale_guard_kernel"] + fwd_names + bwd_names
     assert (k_fwd, k_dq, k_dkdv) == (fwd_names[0], bwd_names[0], bwd_names[1])
     # stage-split calls name the same kernels (plus the preprocess kernel when dQ is not in the call)
-    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_DKDV) == [bwd_names[1]]
-    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_PREP) == ["bwd_prep_kernel"]
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_DKDV, fold) == [bwd_names[1]]
+    assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_PREP, fold) == ["bwd_prep_kernel"]
 
 
 def test_plan_of_option_and_feature_paths():
