@@ -62,6 +62,8 @@ def parse():
                     help="metric: BASELINE.json's headline shape (default); c4: configs[4], forward sharded over the ranks")
     ap.add_argument("--no-extras", action="store_true", help="skip vs_vanilla / variants (rank 0, --gpus 1 only)")
     ap.add_argument("--opts", type=str, default="", help="comma-separated per-call kernel options (fa_mi355x_*_ex), A/B runs only")
+    ap.add_argument("--out-bf16", action="store_true",
+                    help="--config c4: the forward stores O as bf16 (one rounding of the fp32 result), so the gather moves 256 MiB per rank")
     ap.add_argument("--phased", action="store_true",
                     help="profiling A/B only: run the phased (round-1 v5) kernels instead of the MFMA-slot ones")
     return ap.parse_args()
@@ -258,8 +260,10 @@ def main_c4(args):
     gen = torch.Generator(device="cuda").manual_seed(2004 + rank)
     mk = lambda: ((torch.rand((bh, N, d), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
     q, k, v = mk(), mk(), mk()
-    out = torch.empty((bh, N, d), dtype=torch.float32, device="cuda")
+    odt = torch.bfloat16 if args.out_bf16 else torch.float32
+    out = torch.empty((bh, N, d), dtype=odt, device="cuda")
     L = torch.empty((bh, N), dtype=torch.float32, device="cuda")
+    guard = device_ops._auto_guard(q, k, None, "auto")
 
     def barrier():
         dist.barrier()
@@ -281,8 +285,10 @@ def main_c4(args):
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
     it = [0]
 
-    def fwd():
-        device_ops.flash_attn_fwd(q, k, v, False, out=out, l=L)
+    def fwd():   # (the step's scale-guard pass over q, k included: new activations every step)
+        if guard is not None:
+            device_ops.scale_guard(q, k, out=guard)
+        device_ops.flash_attn_fwd(q, k, v, False, out=out, l=L, guard=guard, out_dtype=odt)
 
     def fwd_ev():
         e = ev[it[0] % steps]
@@ -305,7 +311,9 @@ def main_c4(args):
     gsteps = max(2, min(5, steps))
     gather_s = timed(lambda: sharded.all_gather_bh(out, BH_total), gsteps, 1)
     chunks = 4 if bh % 4 == 0 else 1
-    over_s = timed(lambda: sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH_total, False, chunks=chunks), gsteps, 1)
+    cfn = sharded.fwd_bf16_out if args.out_bf16 else None
+    over_s = timed(lambda: sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, BH_total, False, chunks=chunks, compute_fn=cfn, as_view=True),
+                   gsteps, 1)
     flops_total = 4.0 * BH_total * N * N * d
     flops_rank = 4.0 * bh * N * N * d
     if rank == 0:
@@ -315,7 +323,8 @@ def main_c4(args):
             "value": round(flops_total / sec / 1e12, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(sec * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[4]: FlashAttention-2 forward, B={B} H={H} N={N} d={d}, bf16 in / fp32 out, "
+            "config": {"workload": f"BASELINE.json configs[4]: FlashAttention-2 forward, B={B} H={H} N={N} d={d}, bf16 in / "
+                                   f"{'bf16' if args.out_bf16 else 'fp32'} out, "
                                    f"non-causal, {BH_total} (batch, head) pairs cut into {world} contiguous slices ({bh} on rank 0)",
                        "B": B, "H": H, "N": N, "d": d, "causal": False,
                        "parallelism": f"batch*head shard x{world}, one RCCL all-gather of O (timed beside the compute)"},
@@ -325,7 +334,8 @@ def main_c4(args):
                          "avg_launch_ms": round(kern_ms, 4), "flops_per_launch": flops_rank},
             "cpu_baseline": None,
             "gather_ms": round(gather_s * 1e3, 3),
-            "gather_bytes_per_rank": int(out.numel() * 4),
+            "gather_bytes_per_rank": int(out.numel() * out.element_size()),
+            "out_dtype": "bf16" if args.out_bf16 else "fp32",
             "fw_with_gather_overlapped_ms": round(over_s * 1e3, 3),
             "fw_plus_gather_serial_ms": round((sec + gather_s) * 1e3, 3),
             "value_with_gather_overlapped": round(flops_total / over_s / 1e12, 2),

@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <atomic>
 
 #include "../../include/flash_attn_mi355x.h"
 #include "fa_kernels.h"
@@ -98,7 +100,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
   // (round 3 library diet: the values that lost their A/B and had no test -- opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1,
   // opts[4] = 2 (the one-pass backward), opts[6] = 1 -- exist in the diagnostic build only, together with their kernels)
   static const int allowed[NTUN][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1},
-                                       {0, 1, 2, 3, -1}, {0, -1}};
+                                       {0, 1, 2, 3, -1}, {0, 1, -1}};
   for (int i = 0; i < NTUN; ++i) {
     bool ok = false;
     for (int j = 0; allowed[i][j] >= 0; ++j) ok |= allowed[i][j] == t.v[i];
@@ -822,6 +824,7 @@ int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float*
                  float scale = 0.f, const float* guard = nullptr) {
   const float tau = scale > 0.f ? scale : sqrtf(1.0f / (float)d);   // (scale: fa_mi355x_*_scaled; the reference has sqrt(1/d) only)
   lay.young_prio = tun.v[3];
+  lay.out_bf16 = tun.v[9] == 1 ? 1 : 0;
   return run_scaled([&](const Tun& t, const fa::Layout& L) {
     return fwd_dispatch_one(q, k, v, out, l, m, batch, N, dp, L, causal, variant, dtype, st, t, tau);
   }, tun, lay, tau, guard);
@@ -922,6 +925,9 @@ void d2h_rows(float* dst, const float* src, size_t rows, int d, int dp, hipStrea
 // surfaced as the NEXT call's last error) and, worse, left the runtime with a stale pinned range that a later pageable copy into the
 // recycled pages tripped over (an abort from a runtime thread: seen twice in sixteen runs of the GPU suite).  Unregistering clears the
 // sticky error; every host call starts by clearing whatever an earlier HIP user left behind.
+// Process-wide counters of the host launchers' pinning (fa_mi355x_host_pin_stats): merged ranges registered, and ranges that could not
+// be (copied pageable instead: same results, slower).  A regression to "nothing is ever pinned" shows here, not only as time.
+std::atomic<unsigned long long> g_pin_ok{0}, g_pin_fallback{0};
 struct PinSet {
   struct Range { uintptr_t b, e; };
   std::vector<Range> want, held;
@@ -933,7 +939,8 @@ struct PinSet {
   // pinned range as a whole (a copy that starts inside a registered range and runs past its end is an invalid argument to HIP)
   void add(const void* ptr, size_t bytes) {
     if (!enabled() || !ptr || !bytes) return;
-    const uintptr_t page = 4096, a = (uintptr_t)ptr;
+    static const uintptr_t page = [] { const long p = sysconf(_SC_PAGESIZE); return (uintptr_t)(p > 0 ? p : 4096); }();
+    const uintptr_t a = (uintptr_t)ptr;
     want.push_back(Range{a & ~(page - 1), (a + bytes + page - 1) & ~(page - 1)});
   }
   void lock() {
@@ -945,8 +952,13 @@ struct PinSet {
     }
     for (const Range& r : merged) {
       if (r.e - r.b < (4u << 20)) continue;   // (small and on pages of its own: the pageable path costs less than a registration)
-      if (hipHostRegister((void*)r.b, r.e - r.b, hipHostRegisterDefault) == hipSuccess) held.push_back(r);
-      else (void)hipGetLastError();   // (already registered by the caller, or not lockable: copied pageable)
+      if (hipHostRegister((void*)r.b, r.e - r.b, hipHostRegisterDefault) == hipSuccess) {
+        held.push_back(r);
+        g_pin_ok.fetch_add(1, std::memory_order_relaxed);
+      } else {
+        (void)hipGetLastError();   // (already registered by the caller, or not lockable: copied pageable)
+        g_pin_fallback.fetch_add(1, std::memory_order_relaxed);
+      }
     }
   }
   ~PinSet() {
@@ -1317,6 +1329,11 @@ int fa_mi355x_bwd_dropout(const void* q, const void* k, const void* v, const flo
   if (int rc = set_dropout(lay, rate, scale, seed)) return rc;
   return bwd_dispatch(q, k, v, out, out_grad, q_grad, k_grad, v_grad, l, m, (float*)workspace, B * H, N, d, d, lay,
                       causal ? 1 : 0, variant, dtype, FA_BWD_STAGE_ALL, (hipStream_t)stream);
+}
+
+void fa_mi355x_host_pin_stats(unsigned long long* pinned_ranges, unsigned long long* pageable_ranges) {
+  if (pinned_ranges) *pinned_ranges = g_pin_ok.load(std::memory_order_relaxed);
+  if (pageable_ranges) *pageable_ranges = g_pin_fallback.load(std::memory_order_relaxed);
 }
 
 size_t fa_mi355x_guard_bytes(void) { return (size_t)2 * fa::GUARD_SLOTS * sizeof(float); }

@@ -320,6 +320,7 @@ struct Layout {
   const float* guard;
   float guard_coef;      // the operand-rounding estimate in units of its budget is guard_coef * sqrt(max |q|^2 * max |k|^2)
   int guard_want;
+  int out_bf16;          // forward kernels: `o` points to bf16 elements (same shape and row stride), rounded once from the fp32 result
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two

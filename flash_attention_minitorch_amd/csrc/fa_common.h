@@ -65,6 +65,16 @@ FA_DEV bool guard_skip(const Layout& L) {
   return __builtin_amdgcn_readfirstlane((int)beyond) != (L.guard_want != 0);
 }
 
+// Forward epilogue: 4 consecutive columns of one output row, fp32 (the default and the parity path) or bf16 (Layout::out_bf16: one
+// rounding of the fp32 result, 2^-9 relative: for consumers that want a bf16 activation, e.g. the sharded gather of configs[4]).
+FA_DEV void store_out4(float* o, size_t elem_off, const f32x4& val, int out_bf16) {
+  if (out_bf16) {
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(o) + elem_off) = __builtin_convertvector(val, bf16x4);
+  } else {
+    *reinterpret_cast<f32x4*>(o + elem_off) = val;
+  }
+}
+
 FA_DEV f32x16 zero16() {
   f32x16 z;
 #pragma unroll

@@ -250,14 +250,14 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   // a row whose every key is masked has l = 0: it returns O = 0 and L = -inf (and zero gradients in the backward)
   const float inv = (HM && !(l_tot > 0.f)) ? 0.f : 1.0f / l_tot;
   if (qvalid) {
-    float* orow = o + base + (size_t)qrow * ld;
+    const size_t orow = base + (size_t)qrow * ld;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 val = {acc_o[dt][4 * g] * inv, acc_o[dt][4 * g + 1] * inv, acc_o[dt][4 * g + 2] * inv,
                      acc_o[dt][4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = val;
+        store_out4(o, orow + 32 * dt + 8 * g + 4 * h, val, lay.out_bf16);
       }
     if (h == 0) {
       const size_t ri = (size_t)bh * N + qrow;
@@ -829,14 +829,14 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     asm volatile("" : "+v"(qr), "+v"(hh));
   }
   if (qr < N) {
-    float* orow = o + base + (size_t)qr * ld;
+    const size_t orow = base + (size_t)qr * ld;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 val = {acc_o[dt][4 * g] * inv, acc_o[dt][4 * g + 1] * inv, acc_o[dt][4 * g + 2] * inv,
                      acc_o[dt][4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * hh) = val;
+        store_out4(o, orow + 32 * dt + 8 * g + 4 * hh, val, lay.out_bf16);
       }
     if (hh == 0)
       aux_l[(size_t)bh * N + qr] = PRE ? (m_ref + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f : m_ref * tau + __logf(l_tot);

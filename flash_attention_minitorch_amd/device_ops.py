@@ -120,15 +120,26 @@ def _pad_cols(t, dp):
     return torch.nn.functional.pad(t, (0, dp - t.shape[-1]))
 
 
-def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None, guard="auto"):
+def _with_opt(opts, index, value):
+    o = list(opts or ()) + [0] * (index + 1)
+    o[index] = value
+    return tuple(o[:max(index + 1, len(opts or ()))])
+
+
+def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None, guard="auto",
+                   out_dtype=torch.float32):
     """Forward.  Returns (out fp32, l, m): FA-1 -> l = sum exp(s - rowmax), m = rowmax;
     FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*).  ``guard``: "auto" = run the scale-guard pass
     for this call (scale_guard), a tensor = the guard of this (q, k) pair computed before, None = none (fp32 scaling).
+    ``out_dtype`` = torch.bfloat16: the kernels store O as bf16 (one rounding of the fp32 result; option 9; native d only) -- for
+    consumers that take a bf16 activation (sharded.py's gather at half the bytes); the backward needs the fp32 O.
     Any head dim d <= 128: d outside {32, 64, 128} is zero-padded to the next of them on the device (tau keeps the caller's d; the
     reference operator takes any d up to its assert, minitorch/cuda_kernel_ops.py:527-581 / src/flash_attn_fw.cu:43)."""
     bh, n, d = _check_inputs(q, k, v)
     lead = q.shape[:-2]
     if d not in _NATIVE_D:
+        if out_dtype != torch.float32:
+            raise ValueError("a bf16 output needs a native head dim (32, 64, 128)")
         dp = _padded_d(d)
         qp, kp, vp = (_pad_cols(t, dp) for t in (q, k, v))
         outp = torch.empty(lead + (n, dp), dtype=torch.float32, device=q.device)
@@ -143,8 +154,14 @@ def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None,
         else:
             out.copy_(outp[..., :d])
         return out, l, m
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("out_dtype must be float32 or bfloat16")
     if out is None:
-        out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+        out = torch.empty(q.shape, dtype=out_dtype, device=q.device)
+    elif out.dtype != out_dtype or out.shape != q.shape or not out.is_contiguous():
+        raise ValueError("out must be a contiguous tensor of q's shape and of out_dtype")
+    if out_dtype == torch.bfloat16:
+        opts = _with_opt(opts, 9, 1)
     if l is None:
         l = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
     if variant == _lib.FA_VARIANT_FA1 and m is None:

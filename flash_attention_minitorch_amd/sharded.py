@@ -60,6 +60,16 @@ def _default_fwd(q, k, v, causal):
     return o, L
 
 
+def fwd_bf16_out(q, k, v, causal):
+    """compute_fn for the sharded forwards: the HIP kernels store O as bf16 (one rounding of the fp32 result, 2^-9 relative), so the
+    gather moves half the bytes: BASELINE.json configs[4] (FA-2 fw bf16, B=128 H=16 N=4096 d=128 over 8 ranks) gathers 256 MiB per
+    rank instead of 512.  L stays fp32.  Inference / activation-consumer use: the backward needs the fp32 O."""
+    import torch as _t
+    from . import device_ops, _lib
+    o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal, _lib.FA_VARIANT_FA2, out_dtype=_t.bfloat16)
+    return o, L
+
+
 def _default_bwd(q, k, v, o, do, L, causal):
     from . import device_ops, _lib
     return device_ops.flash_attn_bwd(q, k, v, o, do, L, None, causal, _lib.FA_VARIANT_FA2)
@@ -78,15 +88,38 @@ def sharded_flash_attn2_fwd(q_local, k_local, v_local, bh_total: int, causal: bo
     return all_gather_bh(o, bh_total, group), all_gather_bh(L, bh_total, group)
 
 
+def _staged_gather(pieces_of, bh_total, world, chunks, cs, group, as_view):
+    """Shared by the overlapped forward / backward: piece c of every rank is gathered with all_gather_into_tensor straight into
+    stage[c] = [rank][cs][...] (a contiguous destination: the collective writes the final bytes itself, no flat temporary and no copy
+    out, which the list form of all_gather needs on the NCCL / RCCL backend when its destinations are not rank-contiguous).  The stage
+    is [chunk][rank][cs][...]; global batch*head row r * (chunks * cs) + c * cs + i is stage[c][r][i]: returned as that permuted VIEW
+    ([rank][chunk][cs][...], zero copies) when ``as_view``, else as one contiguous [bh_total, ...] tensor (one final permute-copy)."""
+    stages, pending, keep = None, [], []
+    for c in range(chunks):
+        pieces = tuple(p.contiguous() for p in pieces_of(c))
+        if stages is None:
+            stages = tuple(torch.empty((chunks, world, cs) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device) for p in pieces)
+        for st, p in zip(stages, pieces):
+            pending.append(dist.all_gather_into_tensor(st[c].view((world * cs,) + tuple(p.shape[1:])), p, group=group, async_op=True))
+        keep.append(pieces)   # the pieces must outlive their collectives
+    for work in pending:
+        work.wait()
+    views = tuple(st.permute(1, 0, 2, *range(3, st.dim())) for st in stages)
+    if as_view:
+        return views
+    return tuple(v.reshape((bh_total,) + tuple(v.shape[3:])) for v in views)
+
+
 def sharded_flash_attn2_fwd_overlapped(q_local, k_local, v_local, bh_total: int, causal: bool = False, chunks: int = 4,
-                                       group=None, compute_fn: Optional[Callable] = None):
+                                       group=None, compute_fn: Optional[Callable] = None, as_view: bool = False):
     """The same result as sharded_flash_attn2_fwd(..., gather=True) with the all-gather hidden under the compute
-    (at the 8-GPU config the gather of one rank's 256 MiB slice over its xGMI links costs about as
-    much as its forward).  The local slice is cut into ``chunks`` pieces along batch*head; the gather of piece c is issued
-    asynchronously (RCCL runs it on its own stream, ordered after the kernels already queued) and overlaps the kernels
-    of piece c+1; each piece lands directly at its final rows of the [bh_total, ...] outputs, so there is no reshuffle.
-    Needs an even split (bh_total divisible by the world size, the local slice by ``chunks``); otherwise it falls back
-    to the one-shot gather."""
+    (at the 8-GPU config the gather of one rank's slice over its xGMI links costs about as much as its
+    forward).  The local slice is cut into ``chunks`` pieces along batch*head; the gather of piece c is issued asynchronously
+    (RCCL runs it on its own stream, ordered after the kernels already queued) and overlaps the kernels of piece c+1.  Every piece
+    is gathered with all_gather_into_tensor into a [chunk][rank][cs] staging tensor (see _staged_gather); ``as_view`` returns
+    (O, L) as [rank][chunk][cs][...] views of it (no copy at all), the default one contiguous [bh_total, ...] copy each.
+    ``compute_fn=fwd_bf16_out`` halves the bytes of the O gather.  Needs an even split (bh_total divisible by the world size, the
+    local slice by ``chunks``); otherwise it falls back to the one-shot gather."""
     fn = compute_fn or _default_fwd
     world = dist.get_world_size(group)
     bounds = shard_bounds(bh_total, world)
@@ -94,22 +127,12 @@ def sharded_flash_attn2_fwd_overlapped(q_local, k_local, v_local, bh_total: int,
     if len({e - b for b, e in bounds}) != 1 or chunks <= 1 or bh_local % chunks != 0:
         return sharded_flash_attn2_fwd(q_local, k_local, v_local, bh_total, causal, True, group, compute_fn)
     cs = bh_local // chunks
-    o_full = L_full = None
-    pending, keep = [], []
-    for c in range(chunks):
+
+    def pieces_of(c):
         sl = slice(c * cs, (c + 1) * cs)
-        o_c, L_c = fn(q_local[sl], k_local[sl], v_local[sl], causal)
-        o_c, L_c = o_c.contiguous(), L_c.contiguous()
-        if o_full is None:
-            o_full = torch.empty((bh_total,) + tuple(o_c.shape[1:]), dtype=o_c.dtype, device=o_c.device)
-            L_full = torch.empty((bh_total,) + tuple(L_c.shape[1:]), dtype=L_c.dtype, device=L_c.device)
-        rows = [slice(b + c * cs, b + (c + 1) * cs) for b, _ in bounds]
-        pending.append(dist.all_gather([o_full[r] for r in rows], o_c, group=group, async_op=True))
-        pending.append(dist.all_gather([L_full[r] for r in rows], L_c, group=group, async_op=True))
-        keep.append((o_c, L_c))   # the pieces must outlive their collectives
-    for work in pending:
-        work.wait()
-    return o_full, L_full
+        return fn(q_local[sl], k_local[sl], v_local[sl], causal)
+
+    return _staged_gather(pieces_of, bh_total, world, chunks, cs, group, as_view)
 
 
 def sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_local, bh_total: int,
@@ -126,11 +149,12 @@ def sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_loca
 
 def sharded_flash_attn2_bwd_overlapped(q_local, k_local, v_local, o_local, do_local, L_local, bh_total: int,
                                        causal: bool = False, chunks: int = 4, group=None,
-                                       compute_fn: Optional[Callable] = None):
+                                       compute_fn: Optional[Callable] = None, as_view: bool = False):
     """sharded_flash_attn2_bwd(..., gather=True) with the three gradient gathers hidden under the compute, as
     sharded_flash_attn2_fwd_overlapped does for O: the local slice is cut into ``chunks`` pieces along batch*head, the gathers of piece
-    c (dQ, dK, dV: all-gathers, never a reduction -- gradients of different (b, h) do not overlap) run while piece c+1 computes, and
-    every piece lands at its final rows.  Needs an even split; otherwise it falls back to the one-shot gathers."""
+    c (dQ, dK, dV: all-gathers, never a reduction -- gradients of different (b, h) do not overlap) run while piece c+1 computes, each
+    straight into its [chunk][rank][cs] staging tensor (_staged_gather; ``as_view`` as there).  Needs an even split; otherwise it
+    falls back to the one-shot gathers."""
     fn = compute_fn or _default_bwd
     world = dist.get_world_size(group)
     bounds = shard_bounds(bh_total, world)
@@ -139,17 +163,9 @@ def sharded_flash_attn2_bwd_overlapped(q_local, k_local, v_local, o_local, do_lo
         return sharded_flash_attn2_bwd(q_local, k_local, v_local, o_local, do_local, L_local, bh_total, causal, True, group,
                                        compute_fn)
     cs = bh_local // chunks
-    full = None
-    pending, keep = [], []
-    for c in range(chunks):
+
+    def pieces_of(c):
         sl = slice(c * cs, (c + 1) * cs)
-        grads = tuple(g.contiguous() for g in fn(q_local[sl], k_local[sl], v_local[sl], o_local[sl], do_local[sl], L_local[sl], causal))
-        if full is None:
-            full = tuple(torch.empty((bh_total,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device) for g in grads)
-        rows = [slice(b + c * cs, b + (c + 1) * cs) for b, _ in bounds]
-        for dst, g in zip(full, grads):
-            pending.append(dist.all_gather([dst[r] for r in rows], g, group=group, async_op=True))
-        keep.append(grads)   # the pieces must outlive their collectives
-    for work in pending:
-        work.wait()
-    return full
+        return fn(q_local[sl], k_local[sl], v_local[sl], o_local[sl], do_local[sl], L_local[sl], causal)
+
+    return _staged_gather(pieces_of, bh_total, world, chunks, cs, group, as_view)

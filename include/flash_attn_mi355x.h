@@ -76,6 +76,11 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
                               float* q_grad, float* k_grad, float* v_grad, float* l, float* m,
                               int batch, int N, int d, bool causal_mask, void* stream);
 
+/* The host launchers pin the caller's arrays in place for the duration of a call (page-aligned, merged ranges of at least 4 MiB;
+ * hipHostRegister).  Cumulative, process-wide: how many such ranges were registered, and how many could not be (already registered by
+ * the caller, or not lockable) and were copied pageable instead -- same results, slower.  Either pointer may be NULL. */
+void fa_mi355x_host_pin_stats(unsigned long long* pinned_ranges, unsigned long long* pageable_ranges);
+
 /* Forward on device pointers.  q,k,v: dtype elements [batch][N][d]; out: float [batch][N][d];
  * l, m: float [batch][N] (m may be NULL for FA_VARIANT_FA2).  Asynchronous on `stream`. */
 int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float* l, float* m,
@@ -144,7 +149,10 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *            that q and k are of the north star's U(-1, 1) magnitude: the MFMA-slot kernels that fold tau*log2(e) into a bf16
  *            operand run unguarded (8-10 % faster; at x2 inputs their error on O doubles to 1.4e-3); 2 = fp32 scaling whatever a
  *            guard says; 3 = fa_mi355x_plan only: plan a guarded call (both launches of every pair)
- *   opts[9]  unused
+ *   opts[9]  forward only: 1 = `out` points to BF16 elements of the same shape and row stride (one rounding of the fp32 result, 2^-9
+ *            relative: |error| <= 2e-3 |o|, i.e. above the 1e-3 parity bound once |o| > 0.5; fp32 stays the default and the parity
+ *            path).  For consumers that take a bf16 activation, e.g. the sharded gather of BASELINE configs[4] at half the bytes.  The
+ *            backward needs the fp32 `out` of a default forward.
  * Values that lost their A/B (opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1, opts[4] = 2 / 3 = the one-pass
  * backwards, opts[6] = 1) exist in the diagnostic library only; the product library answers them with FA_ERR_BAD_ARG.
  * Every value selects kernels with the same results within the stated tolerances; stamp / ablation builds are not in this

@@ -198,3 +198,10 @@ def test_product_path_does_not_import_oracle():
             "flash_attention_minitorch_amd.sharded; assert not any(m == 'oracle' or m.startswith('oracle.') "
             "for m in sys.modules)")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_native_backtrace_hook_fires_on_abort(tmp_path):
+    """tests/abort_trace.c (the SIGABRT / SIGSEGV hook of the GPU runs) is itself tested: see gpu_util.check_abort_hook."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import check_abort_hook
+    check_abort_hook(tmp_path)

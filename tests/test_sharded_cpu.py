@@ -51,6 +51,14 @@ def _worker(rank, world, port, bh_total, causal, out_dir, N=24, d=16, chunks=Non
         g2 = sharded.sharded_flash_attn2_bwd_overlapped(q, k, v, o_loc, do, L_loc, bh_total, causal,
                                                         chunks=chunks or (3 if (e - b) % 3 == 0 else 2), compute_fn=_oracle_bwd)
         assert all(torch.equal(a, b_) for a, b_ in zip(g2, (dq, dk, dv)))
+        # round 4: every piece lands by all_gather_into_tensor in a [chunk][rank][cs] staging tensor; as_view returns it permuted to
+        # [rank][chunk][cs] (global batch*head order, no copy); a compute_fn with a bf16 O halves the bytes of that gather
+        if (e - b) * world == bh_total and (e - b) % 2 == 0:
+            ov, Lv = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, bh_total, causal, chunks=2, compute_fn=_oracle_fwd, as_view=True)
+            assert ov.shape[:3] == (world, 2, (e - b) // 2) and torch.equal(ov.reshape(o.shape), o) and torch.equal(Lv.reshape(L.shape), L)
+            bf = lambda q_, k_, v_, c_: (lambda oo, LL: (oo.to(torch.bfloat16), LL))(*_oracle_fwd(q_, k_, v_, c_))
+            o16, _ = sharded.sharded_flash_attn2_fwd_overlapped(q, k, v, bh_total, causal, chunks=2, compute_fn=bf)
+            assert o16.dtype == torch.bfloat16 and torch.equal(o16, o.to(torch.bfloat16))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), o=o.numpy(), L=L.numpy(), dq=dq.numpy(), dk=dk.numpy(),
                  dv=dv.numpy())
     finally:
