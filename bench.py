@@ -87,14 +87,15 @@ def guarded_call(BH, N, d, causal, dtype, opts):
     return len(two) > len(one)
 
 
-def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd, guard_fn=None):
+def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd, guarded=False):
     """The step as a list of (kernel name, callable) in the library's own launch order, from fa_mi355x_plan.  A backward plan without
     bwd_prep_kernel means the dQ launch preprocesses its own rows and runs first; bwd_fused_kernel is the opt-in one-pass backward.
-    guard_fn (a guarded step): the scale-guard pass comes first, and every stage is the launch of the named kernel plus the launch of
-    its fp32-scaling twin, which returns at once for operands inside the guard's budget (the names are those of the chosen side)."""
+    guarded (a step under the scale guard): every stage is the launch of the named kernel plus the launch of its fp32-scaling twin,
+    which returns at once for operands inside the guard's budget (the names are those of the chosen side); the forward stage also
+    zero-fills the 2-KiB guard that its launch then fills."""
     from flash_attention_minitorch_amd import _lib
     dt = _lib.FA_DTYPE_BF16 if dtype == "bf16" else _lib.FA_DTYPE_F32
-    popts = with_scale_mode(opts, 1) if guard_fn is not None else opts
+    popts = with_scale_mode(opts, 1) if guarded else opts
     plan = lambda stages: _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, stages, popts)
     main = lambda names: [n for n in names if n != "bwd_prep_kernel"][0]   # (a follow-up launch of the same kernel follows its main one)
     k_fwd = main(plan(0))
@@ -109,8 +110,6 @@ def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd, guard_fn=Non
     else:
         stages = ((k_fwd, fwd), (k_dq, lambda: bwd(device_ops.STAGE_PREP | device_ops.STAGE_DQ)),
                   (k_dkdv, lambda: bwd(device_ops.STAGE_DKDV)))
-    if guard_fn is not None:
-        stages = (("scale_guard_kernel", guard_fn),) + stages
     return stages, k_fwd, k_dq, k_dkdv
 
 
@@ -125,13 +124,11 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
     o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal)
     ws = device_ops.bwd_workspace(q)
     grads = tuple(torch.empty(q.shape, dtype=torch.float32, device="cuda") for _ in range(3))
-    # (the default calls run under the scale guard: its pass over q, k belongs to the forward; the backward takes the same guard)
-    g0 = device_ops._auto_guard(q, k, None, "auto")
+    # (the default calls run under the scale guard: the forward fills it, the backward takes the same guard)
+    g0 = device_ops.new_guard(q)
 
     def f_fw():
-        if g0 is not None:
-            device_ops.scale_guard(q, k, out=g0)
-        device_ops.flash_attn_fwd(q, k, v, causal, out=o, l=L, guard=g0)
+        device_ops.flash_attn_fwd(q, k, v, causal, out=o, l=L, guard=g0, produce_guard=True)
 
     def f_fwbw():
         f_fw()
@@ -175,14 +172,7 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
         mk = lambda: ((torch.rand((BH_, N_, d_), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
         qq, kk, vv = mk(), mk(), mk()
         oo, ll, _ = device_ops.flash_attn_fwd(qq, kk, vv, False)
-        gg = device_ops._auto_guard(qq, kk, None, "auto")
-
-        def one():
-            if gg is not None:
-                device_ops.scale_guard(qq, kk, out=gg)
-            device_ops.flash_attn_fwd(qq, kk, vv, False, out=oo, l=ll, guard=gg)
-
-        tf = vg.time_ms(one, 20, 5)
+        tf = vg.time_ms(lambda: device_ops.flash_attn_fwd(qq, kk, vv, False, out=oo, l=ll), 20, 5)
         tfl = 4.0 * BH_ * N_ * N_ * d_ / tf / 1e9
         return {"ms_tflops_frac": [round(tf, 4), round(tfl, 1), round(tfl / PEAK_BF16_TFLOPS, 4)]}
 
@@ -193,12 +183,8 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
         oo, ll, mm = device_ops.flash_attn_fwd(qq, kk, vv, caus, variant)
         w2 = device_ops.bwd_workspace(qq)
         gg = tuple(torch.empty(qq.shape, dtype=torch.float32, device="cuda") for _ in range(3))
-        gd = device_ops._auto_guard(qq, kk, None, "auto")
-
-        def fw():
-            if gd is not None:
-                device_ops.scale_guard(qq, kk, out=gd)
-            device_ops.flash_attn_fwd(qq, kk, vv, caus, variant, out=oo, l=ll, m=mm, guard=gd)
+        gd = device_ops.new_guard(qq)
+        fw = lambda: device_ops.flash_attn_fwd(qq, kk, vv, caus, variant, out=oo, l=ll, m=mm, guard=gd, produce_guard=True)
 
         bw = lambda: device_ops.flash_attn_bwd(qq, kk, vv, oo, dd, ll, mm, caus, variant, workspace=w2, grads=gg, guard=gd)
         tf, tb = vg.time_ms(fw, iters, warm), vg.time_ms(bw, iters, warm)
@@ -263,8 +249,6 @@ def main_c4(args):
     odt = torch.bfloat16 if args.out_bf16 else torch.float32
     out = torch.empty((bh, N, d), dtype=odt, device="cuda")
     L = torch.empty((bh, N), dtype=torch.float32, device="cuda")
-    guard = device_ops._auto_guard(q, k, None, "auto")
-
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
@@ -285,10 +269,8 @@ def main_c4(args):
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
     it = [0]
 
-    def fwd():   # (the step's scale-guard pass over q, k included: new activations every step)
-        if guard is not None:
-            device_ops.scale_guard(q, k, out=guard)
-        device_ops.flash_attn_fwd(q, k, v, False, out=out, l=L, guard=guard, out_dtype=odt)
+    def fwd():   # (the default call: under the scale guard, formed inside the forward's own launch)
+        device_ops.flash_attn_fwd(q, k, v, False, out=out, l=L, out_dtype=odt)
 
     def fwd_ev():
         e = ev[it[0] % steps]
@@ -388,16 +370,14 @@ def main():
     grads = tuple(torch.empty((BH, N, d), dtype=torch.float32, device="cuda") for _ in range(3))
     ws = device_ops.bwd_workspace(q)
 
-    # The default call runs under the scale guard (include/flash_attn_mi355x.h): ONE pass over q and k per step (inside the timed
-    # region: a training step sees new q, k every time), whose result the forward and the backward launches read on the device.
+    # The default call runs under the scale guard (include/flash_attn_mi355x.h): every step's forward forms the row norms of its q, k
+    # inside its own launch (inside the timed region: a training step sees new q, k every time), its fp32-scaling twin and the
+    # backward's launches read the result on the device.
     GUARDED = guarded_call(BH, N, d, causal, args.dtype, OPTS)
-    guard = device_ops.scale_guard(q, k) if GUARDED else None
+    guard = device_ops.new_guard(q, OPTS) if GUARDED else None
 
-    def guard_pass():
-        device_ops.scale_guard(q, k, out=guard)
-
-    def fwd():
-        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L, opts=OPTS, guard=guard)
+    def fwd():   # (fills the guard inside its own launch; the backward's launches read it)
+        device_ops.flash_attn_fwd(q, k, v, causal, out=out, l=L, opts=OPTS, guard=guard, produce_guard=GUARDED)
 
     def bwd(stages=device_ops.STAGE_ALL):
         device_ops.flash_attn_bwd(q, k, v, out, do, L, None, causal, workspace=ws, grads=grads, stages=stages, opts=OPTS, guard=guard)
@@ -406,7 +386,7 @@ def main():
     # kernels INSIDE the timed region (same stream, same kernels, same order as fa_mi355x_bwd).  Which kernels those are, and in which
     # order, is asked of the library (fa_mi355x_plan runs its dispatch code with the launches skipped): kernel names as rocprofv3
     # shows them (fa::<name><...>).
-    STAGES, K_FWD, K_DQ, K_DKDV = stage_plan(device_ops, BH, N, d, causal, args.dtype, OPTS, fwd, bwd, guard_pass if GUARDED else None)
+    STAGES, K_FWD, K_DQ, K_DKDV = stage_plan(device_ops, BH, N, d, causal, args.dtype, OPTS, fwd, bwd, GUARDED)
     breakdown = not args.no_kernel_breakdown
 
     def step(ev=None, only=-1):
@@ -602,9 +582,9 @@ def main():
             "kernels_ms_sum_note": "the entries come from two passes (see kernels_ms_source) and the untimed pass carries an event at "
                                    "every kernel boundary (~3 us each): their sum is NOT ms_per_step and may exceed it by a few us",
             "scale_guard": {"guarded": GUARDED,
-                            "what": "the step starts with scale_guard_kernel (one pass over q, k); the forward, dQ and dK/dV stages "
-                                    "each launch the named kernel and its fp32-scaling twin, which returns at once for operands "
-                                    "inside the guard's budget: both launches are inside the stage's time"
+                            "what": "the forward launch forms the row norms of q, k itself (2-KiB memset in front of it); the forward, dQ "
+                                    "and dK/dV stages each launch the named kernel and its fp32-scaling twin, which returns at once "
+                                    "for operands inside the guard's budget: all of it inside the stages' times"
                                     if GUARDED else "no kernel of this call folds the softmax scale into an operand"},
             "settle_ms": round(settle_ms, 1),
             "ms_per_step_blocks": blocks_ms,

@@ -123,7 +123,7 @@ def core() -> ctypes.CDLL:
     h.fa_mi355x_guard_bytes.restype = ctypes.c_size_t
     h.fa_mi355x_scale_guard.argtypes = [_vp, _vp, ctypes.c_long, _i, _i, _vp, _vp]
     h.fa_mi355x_scale_guard.restype = _i
-    h.fa_mi355x_fwd_guarded.argtypes = [_vp] * 6 + [_i] * 5 + [ctypes.c_float] + [_i] * 3 + [_ip, _i, _vp, _vp]
+    h.fa_mi355x_fwd_guarded.argtypes = [_vp] * 6 + [_i] * 5 + [ctypes.c_float] + [_i] * 3 + [_ip, _i, _vp, _i, _vp]
     h.fa_mi355x_fwd_guarded.restype = _i
     h.fa_mi355x_bwd_guarded.argtypes = [_vp] * 11 + [_i] * 5 + [ctypes.c_float] + [_i] * 4 + [_ip, _i, _vp, _vp]
     h.fa_mi355x_bwd_guarded.restype = _i

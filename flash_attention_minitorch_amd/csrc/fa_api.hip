@@ -46,7 +46,7 @@ int set_err(int code, const char* what, hipError_t e = hipSuccess) {
 thread_local std::vector<std::string>* t_plan = nullptr;
 // A second dry-run mode, for run_scaled below: the dispatch code runs with every launch and HIP call skipped and nothing recorded but
 // t_fold: did the selection reach a kernel that carries tau*log2(e) in a bf16 operand (FA_LAUNCH_FOLD sites)?
-thread_local bool t_probe = false, t_fold = false;
+thread_local bool t_probe = false, t_fold = false, t_fold_produces = false;   // (..._produces: the folding launch can fill the guard itself)
 bool plan_mode() { return t_plan != nullptr || t_probe; }
 void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> "fwd_slot_kernel"
   const char* b = expr;
@@ -67,6 +67,12 @@ void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> 
   do {                                                                      \
     t_fold = true;                                                          \
     FA_LAUNCH(kern, grid, block, shmem, st, __VA_ARGS__);                   \
+  } while (0)
+// ... and can fill the call's scale guard inside its own launch (the non-causal builds of the slot forward: guard_produce)
+#define FA_LAUNCH_FOLD_P(kern, grid, block, shmem, st, ...)                 \
+  do {                                                                      \
+    t_fold_produces = true;                                                 \
+    FA_LAUNCH_FOLD(kern, grid, block, shmem, st, __VA_ARGS__);              \
   } while (0)
 
 inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
@@ -261,14 +267,14 @@ int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l
 #endif
       if (whole && (tun.v[1] != 6 || !diag_stk) && D == 64) {   // d = 64 default: 64-key stages (64 KiB of rings), two workgroups per CU = four
         // waves per SIMD at 122 VGPRs: 0.268 vs 0.282 ms for the 128-key-stage build at two waves per SIMD (tuning key 1 = 6)
-        FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_FOLD_P((fa::fwd_slot_kernel<T, 64, false, 0, 64, 4>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
         FA_HIP_TRY(hipGetLastError());
         return FA_OK;
       }
       if constexpr (D == 128 || diag_stk) {
         if (whole) {
-          FA_LAUNCH_FOLD((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
+          FA_LAUNCH_FOLD_P((fa::fwd_slot_kernel<T, D, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q,
                              (const T*)k, (const T*)v, out, l, N, nqb, batch, lay, causal, tau);
           FA_HIP_TRY(hipGetLastError());
           return FA_OK;
@@ -783,8 +789,12 @@ inline Tun exact_tun(Tun t) {   // the kernels that scale every score in fp32 (t
   t.v[2] = 2;
   return t;
 }
-template <class F>
-int run_scaled(F&& run, const Tun& tun, fa::Layout lay, float tau, const float* guard) {
+// produce (forward calls only, option 8 = 0): the call FILLS `guard` instead of reading it, so that the backward of the same (q, k)
+// can take it: a forward that folds produces it inside its own launch (fa_common.h: guard_produce: no separate pass over q and k;
+// the launch runs with the folded scale and its fp32-scaling twin, behind it, redoes the call if the finished guard says so);
+// a forward whose selection folds nothing runs the separate pass (guard_pass), because the backward of the same call may fold.
+template <class F, class Z, class G>
+int run_scaled(F&& run, const Tun& tun, fa::Layout lay, float tau, const float* guard, int produce, Z&& zero_guard, G&& guard_pass) {
   const float c = tau * fa::LOG2E;
   const int mode = tun.v[8];
   if (mode == 1 || fabsf(c - 1.0f) < 1e-6f) return run(tun, lay);
@@ -793,20 +803,51 @@ int run_scaled(F&& run, const Tun& tun, fa::Layout lay, float tau, const float* 
     std::vector<std::string>* keep = t_plan;
     t_plan = nullptr;
     t_probe = true;
-    t_fold = false;
+    t_fold = t_fold_produces = false;
     const int rc = run(tun, lay);
     t_probe = false;
     t_plan = keep;
     if (rc) return rc;
-    if (!t_fold) return run(tun, lay);
+    if (!t_fold) {
+      if (produce && guard && mode == 0)
+        if (const int rc2 = guard_pass()) return rc2;
+      return run(tun, lay);
+    }
   }
   if (mode == 2 || !guard) return run(exact_tun(tun), lay);
   lay.guard = guard;
   lay.guard_coef = c * (0.001953125f * 0.57735027f) / GUARD_BUDGET;
-  lay.guard_want = 0;
+  if (produce && t_fold_produces) {
+    if (const int rc = zero_guard()) return rc;
+    lay.guard_want = 2;
+  } else {
+    if (produce)   // (a folding forward that cannot fill the guard itself: the causal slot build)
+      if (const int rc = guard_pass()) return rc;
+    lay.guard_want = 0;
+  }
   if (const int rc = run(tun, lay)) return rc;
   lay.guard_want = 1;
   return run(exact_tun(tun), lay);
+}
+
+int launch_scale_guard(const void* q, const void* k, long rows, int row_elems, int dtype, void* guard, hipStream_t st) {
+  // only bf16 rows of 64 / 128 elements ever reach a kernel that folds the scale into an operand: everything else gets an all-zero
+  // guard ("within the budget"; those calls run fp32-scaling kernels whatever it says)
+  if (dtype != FA_DTYPE_BF16 || (row_elems != 64 && row_elems != 128)) {
+    FA_HIP_TRY(hipMemsetAsync(guard, 0, (size_t)2 * fa::GUARD_SLOTS * sizeof(float), st));
+    return FA_OK;
+  }
+  if (plan_mode()) {
+    if (t_plan) t_plan->emplace_back("scale_guard_kernel");
+    return FA_OK;
+  }
+  const dim3 grid(fa::GUARD_SLOTS, 2);
+  if (row_elems == 64)
+    hipLaunchKernelGGL((fa::scale_guard_kernel<64>), grid, dim3(256), 0, st, (const fa::bf16_t*)q, (const fa::bf16_t*)k, rows, (float*)guard);
+  else
+    hipLaunchKernelGGL((fa::scale_guard_kernel<128>), grid, dim3(256), 0, st, (const fa::bf16_t*)q, (const fa::bf16_t*)k, rows, (float*)guard);
+  FA_HIP_TRY(hipGetLastError());
+  return FA_OK;
 }
 
 int fwd_dispatch_one(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int dp,
@@ -821,13 +862,19 @@ int bwd_dispatch_one(const void* q, const void* k, const void* v, const float* o
 
 int fwd_dispatch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N, int d,
                  int dp, fa::Layout lay, int causal, int variant, int dtype, hipStream_t st, const Tun& tun = default_tun(),
-                 float scale = 0.f, const float* guard = nullptr) {
+                 float scale = 0.f, const float* guard = nullptr, int produce = 0) {
   const float tau = scale > 0.f ? scale : sqrtf(1.0f / (float)d);   // (scale: fa_mi355x_*_scaled; the reference has sqrt(1/d) only)
   lay.young_prio = tun.v[3];
   lay.out_bf16 = tun.v[9] == 1 ? 1 : 0;
   return run_scaled([&](const Tun& t, const fa::Layout& L) {
     return fwd_dispatch_one(q, k, v, out, l, m, batch, N, dp, L, causal, variant, dtype, st, t, tau);
-  }, tun, lay, tau, guard);
+  }, tun, lay, tau, guard, produce,
+  [&]() -> int {
+    if (t_plan) { t_plan->emplace_back("memset"); return FA_OK; }
+    FA_HIP_TRY(hipMemsetAsync(const_cast<float*>(guard), 0, (size_t)2 * fa::GUARD_SLOTS * sizeof(float), st));
+    return FA_OK;
+  },
+  [&]() -> int { return launch_scale_guard(q, k, (long)batch * N, dp, dtype, const_cast<float*>(guard), st); });
 }
 
 int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, const void* dout, float* dq, float* dk,
@@ -838,7 +885,7 @@ int bwd_dispatch(const void* q, const void* k, const void* v, const float* out, 
   lay.young_prio = tun.v[3];
   return run_scaled([&](const Tun& t, const fa::Layout& L) {
     return bwd_dispatch_one(q, k, v, out, dout, dq, dk, dv, l, m, ws, batch, N, dp, L, causal, variant, dtype, stages, st, t, tau);
-  }, tun, lay, tau, guard);
+  }, tun, lay, tau, guard, 0, []() -> int { return FA_OK; }, []() -> int { return FA_OK; });
 }
 
 int check_common(int batch, int N, int d, int variant, int dtype) {
@@ -1342,31 +1389,19 @@ int fa_mi355x_scale_guard(const void* q, const void* k, long rows, int row_elems
   g_err[0] = 0;
   if (!q || !k || !guard || rows <= 0) return set_err(FA_ERR_BAD_ARG, "bad argument");
   if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_BF16) return set_err(FA_ERR_BAD_ARG, "unknown dtype");
-  hipStream_t st = (hipStream_t)stream;
-  // only bf16 rows of 64 / 128 elements ever reach a kernel that folds the scale into an operand: everything else gets an all-zero
-  // guard ("within the budget"; those calls run fp32-scaling kernels whatever it says)
-  if (dtype != FA_DTYPE_BF16 || (row_elems != 64 && row_elems != 128)) {
-    FA_HIP_TRY(hipMemsetAsync(guard, 0, fa_mi355x_guard_bytes(), st));
-    return FA_OK;
-  }
-  const dim3 grid(fa::GUARD_SLOTS, 2);
-  if (row_elems == 64)
-    hipLaunchKernelGGL((fa::scale_guard_kernel<64>), grid, dim3(256), 0, st, (const fa::bf16_t*)q, (const fa::bf16_t*)k, rows, (float*)guard);
-  else
-    hipLaunchKernelGGL((fa::scale_guard_kernel<128>), grid, dim3(256), 0, st, (const fa::bf16_t*)q, (const fa::bf16_t*)k, rows, (float*)guard);
-  FA_HIP_TRY(hipGetLastError());
-  return FA_OK;
+  return launch_scale_guard(q, k, rows, row_elems, dtype, guard, (hipStream_t)stream);
 }
 
 int fa_mi355x_fwd_guarded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H, int N, int d,
                           int layout, float softmax_scale, int causal, int variant, int dtype, const int* opts, int nopts,
-                          const void* guard, void* stream) {
+                          void* guard, int produce_guard, void* stream) {
   g_err[0] = 0;
   Tun tun;
   if (int rc = parse_opts(opts, nopts, tun)) return rc;
   if (B <= 0 || H <= 0) return set_err(FA_ERR_BAD_ARG, "B and H must be positive");
   if (int rc = check_common(B * H, N, d, variant, dtype)) return rc;
   if (!q || !k || !v || !out || !l || (variant == FA_VARIANT_FA1 && !m)) return set_err(FA_ERR_BAD_ARG, "null pointer argument");
+  if (produce_guard && !guard) return set_err(FA_ERR_BAD_ARG, "produce_guard needs a guard buffer");
   if (!d_supported(d)) return set_err(FA_ERR_UNSUPPORTED_D, "device path supports d in {32, 64, 128}");
   if (layout != FA_LAYOUT_BHND && layout != FA_LAYOUT_BNHD) return set_err(FA_ERR_BAD_ARG, "unknown layout");
   if (softmax_scale != 0.f && (!(softmax_scale > 0.f) || !std::isfinite(softmax_scale)))
@@ -1374,7 +1409,7 @@ int fa_mi355x_fwd_guarded(const void* q, const void* k, const void* v, float* ou
   if ((long)N * H * d * 4 >= (1L << 31)) return set_err(FA_ERR_BAD_ARG, "one batch element must stay under 2 GiB");
   const fa::Layout lay = layout == FA_LAYOUT_BNHD ? bnhd(H, N, d) : bhnd(N, d);
   return fwd_dispatch(q, k, v, out, l, m, B * H, N, d, d, lay, causal ? 1 : 0, variant, dtype, (hipStream_t)stream, tun,
-                      softmax_scale, (const float*)guard);
+                      softmax_scale, (const float*)guard, produce_guard ? 1 : 0);
 }
 
 int fa_mi355x_bwd_guarded(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,

@@ -51,7 +51,7 @@ template <> FA_DEV f32x8 load_frag_buf<float>(rsrc_t rs, int byte_off) {
 // Everything is wave-uniform after the reduction; a launch without a guard (Layout::guard == nullptr) pays one scalar branch.
 constexpr int GUARD_SLOTS = 256;
 FA_DEV bool guard_skip(const Layout& L) {
-  if (L.guard == nullptr) return false;
+  if (L.guard == nullptr || L.guard_want == 2) return false;   // (2: this launch PRODUCES the guard, see guard_produce)
   const int lane = threadIdx.x & 63;
   const f32x4 a = *reinterpret_cast<const f32x4*>(L.guard + 4 * lane);
   const f32x4 b = *reinterpret_cast<const f32x4*>(L.guard + GUARD_SLOTS + 4 * lane);
@@ -63,6 +63,33 @@ FA_DEV bool guard_skip(const Layout& L) {
   }
   const bool beyond = !(L.guard_coef * __builtin_sqrtf(qm * km) <= 1.0f);   // (NaN / Inf inputs count as beyond)
   return __builtin_amdgcn_readfirstlane((int)beyond) != (L.guard_want != 0);
+}
+
+// The forward can produce the guard itself instead of a separate pass over q and k (Layout::guard_want == 2, a zero-filled guard):
+// every wave of a mask-free slot forward holds the fragments of its 32 query rows anyway and loads the 32 KEY rows of the same
+// indices beside them (the query blocks of a head cover 0..N-1, so the key rows of a head are covered exactly once as well); the
+// wave's largest squared row norms go to slot (blockIdx & 255) with an atomic max on the float bits (non-negative floats order like
+// unsigned integers; a NaN row reads as "beyond the budget").  Optimistic: the launch itself runs with the folded scale, and its
+// fp32-scaling twin, launched behind it, redoes the call if the finished guard says so.  qs / ks: the lane's half-row sums of squares.
+FA_DEV void guard_produce(const Layout& L, float qs, float ks) {
+  qs = xhalf_sum(qs);
+  ks = xhalf_sum(ks);
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    qs = fmaxf(qs, __shfl_xor(qs, off));
+    ks = fmaxf(ks, __shfl_xor(ks, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* g = reinterpret_cast<unsigned*>(const_cast<float*>(L.guard)) + (blockIdx.x & (GUARD_SLOTS - 1));
+    atomicMax(g, __float_as_uint(qs));
+    atomicMax(g + GUARD_SLOTS, __float_as_uint(ks));
+  }
+}
+template <typename F> FA_DEV float frag_sumsq(const F& f) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s = __builtin_fmaf((float)f[j], (float)f[j], s);
+  return s;
 }
 
 // Forward epilogue: 4 consecutive columns of one output row, fp32 (the default and the parity path) or bf16 (Layout::out_bf16: one

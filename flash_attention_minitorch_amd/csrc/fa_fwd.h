@@ -443,6 +443,17 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   frag qf[KC];
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
+  // (not the causal build: it sits at its 128 registers and spilled two around this; causal calls take the separate guard pass)
+  if (PRE && !CDIAG && lay.guard_want == 2 && lay.guard != nullptr) {   // this launch produces the call's scale guard (fa_common.h: guard_produce)
+    const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+    float qs = 0.f, ks = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      qs += frag_sumsq(qf[kc]);
+      ks += frag_sumsq(load_frag_buf<T>(krs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T)));
+    }
+    guard_produce(lay, qs, ks);
+  }
   const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform: rows with fewer than 64 admissible keys (query block 0 only)
   if (PRE && !exactq) {
 #pragma unroll

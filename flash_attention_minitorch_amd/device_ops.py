@@ -88,15 +88,26 @@ def scale_guard(q, k, out=None):
     return out
 
 
+def _wants_guard(q, opts):
+    """Could a folded-scale kernel run for these operands (bf16, d = 64 / 128, option 8 left at 0)?"""
+    if _lib.DIAG:
+        return False   # (tools/ on the diagnostic library: its process-wide default is the folded scale, option 8 = 1)
+    return q.dtype == torch.bfloat16 and q.shape[-1] in (64, 128) and _scale_mode(opts) == 0
+
+
+def new_guard(q, opts=None):
+    """An empty guard for a forward call to FILL (flash_attn_fwd(..., guard=g, produce_guard=True)) and the backward of the same
+    (q, k) to read; None where no kernel of the call could fold the scale."""
+    if not _wants_guard(q, opts):
+        return None
+    return torch.empty(_lib.core().fa_mi355x_guard_bytes() // 4, dtype=torch.float32, device=q.device)
+
+
 def _auto_guard(q, k, opts, guard):
-    """guard = "auto" (the default): a guard pass where a folded-scale kernel could run (bf16, d = 64 / 128, option 8 left at 0)."""
+    """guard = "auto" on a call that only READS a guard (the backward on its own): the separate pass over q and k."""
     if not isinstance(guard, str):
         return guard
-    if _lib.DIAG:
-        return None   # (tools/ on the diagnostic library: its process-wide default is the folded scale, option 8 = 1)
-    if q.dtype != torch.bfloat16 or q.shape[-1] not in (64, 128) or _scale_mode(opts) != 0:
-        return None
-    return scale_guard(q, k)
+    return scale_guard(q, k) if _wants_guard(q, opts) else None
 
 
 OPTS_ONE_PASS_BWD = (0, 0, 0, 0, 2)   # DIAGNOSTIC LIBRARY ONLY (tools/check_fused.py): dQ inside the key-stationary kernel, ordered hand-off
@@ -127,10 +138,12 @@ def _with_opt(opts, index, value):
 
 
 def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None, l=None, m=None, opts=None, guard="auto",
-                   out_dtype=torch.float32):
+                   out_dtype=torch.float32, produce_guard=False):
     """Forward.  Returns (out fp32, l, m): FA-1 -> l = sum exp(s - rowmax), m = rowmax;
-    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*).  ``guard``: "auto" = run the scale-guard pass
-    for this call (scale_guard), a tensor = the guard of this (q, k) pair computed before, None = none (fp32 scaling).
+    FA-2 -> l = logsumexp, m = None.  ``opts``: per-call kernel options (see OPTS_*).  ``guard``: "auto" = the call guards itself (a
+    forward with the folded scale forms the row norms of q and k inside its own launch and its fp32-scaling twin redoes the call if
+    they are beyond the budget); a tensor with ``produce_guard`` = the same, and the tensor (new_guard) is FILLED for the backward of
+    this (q, k); a tensor without = a guard computed before (scale_guard); None = none (fp32 scaling).
     ``out_dtype`` = torch.bfloat16: the kernels store O as bf16 (one rounding of the fp32 result; option 9; native d only) -- for
     consumers that take a bf16 activation (sharded.py's gather at half the bytes); the backward needs the fp32 O.
     Any head dim d <= 128: d outside {32, 64, 128} is zero-padded to the next of them on the device (tau keeps the caller's d; the
@@ -167,10 +180,11 @@ def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None,
     if variant == _lib.FA_VARIANT_FA1 and m is None:
         m = torch.empty(lead + (n,), dtype=torch.float32, device=q.device)
     arr, cnt = _lib.opts_array(opts)
-    guard = _auto_guard(q, k, opts, guard)
+    if isinstance(guard, str):
+        guard, produce_guard = new_guard(q, opts), True
     _lib.check(_lib.core().fa_mi355x_fwd_guarded(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), bh, 1, n, d,
                                                  _lib.FA_LAYOUT_BHND, 0.0, int(bool(causal)), variant, _DTYPES[q.dtype], arr, cnt,
-                                                 _ptr(guard), _stream_ptr()))
+                                                 _ptr(guard), int(bool(produce_guard and guard is not None)), _stream_ptr()))
     return out, l, m
 
 
@@ -239,7 +253,8 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
     return dq, dk, dv
 
 
-def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None, guard="auto", opts=None):
+def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, softmax_scale=None, guard="auto", opts=None,
+                        produce_guard=False):
     """Forward on (B, N, H, d) tensors -- the layout minitorch's projection writes before its
     permute(0,2,1,3).contiguous() (minitorch/modules_transfomer.py:67-89): no head-split copies.
     Returns (out (B, N, H, d) fp32, l (B, H, N), m (B, H, N) or None).
@@ -255,10 +270,12 @@ def flash_attn_fwd_bnhd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, soft
     l = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
     m = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if variant == _lib.FA_VARIANT_FA1 else None
     arr, cnt = _lib.opts_array(opts)
-    guard = _auto_guard(q, k, opts, guard)   # (with softmax_scale = ln 2 the library ignores it: the folded factor is 1)
+    if isinstance(guard, str):   # (with softmax_scale = ln 2 the library ignores it: the folded factor is 1)
+        guard, produce_guard = new_guard(q, opts), True
     _lib.check(_lib.core().fa_mi355x_fwd_guarded(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(l), _ptr(m), B, H, N, d,
                                                  _lib.FA_LAYOUT_BNHD, float(softmax_scale or 0.0), int(bool(causal)), variant,
-                                                 _DTYPES[q.dtype], arr, cnt, _ptr(guard), _stream_ptr()))
+                                                 _DTYPES[q.dtype], arr, cnt, _ptr(guard), int(bool(produce_guard and guard is not None)),
+                                                 _stream_ptr()))
     return out, l, m
 
 
@@ -354,8 +371,8 @@ class _FlashAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, causal, variant):
-        guard = _auto_guard(q, k, None, "auto") if q.shape[-1] in _NATIVE_D else None   # ONE pass over q, k for forward and backward
-        o, l, m = flash_attn_fwd(q, k, v, causal, variant, guard=guard)
+        guard = new_guard(q) if q.shape[-1] in _NATIVE_D else None   # filled by the forward's own launch, read by the backward
+        o, l, m = flash_attn_fwd(q, k, v, causal, variant, guard=guard, produce_guard=True)
         none = torch.empty(0, device=q.device)
         ctx.save_for_backward(q, k, v, o, l, m if m is not None else none, guard if guard is not None else none)
         ctx.causal, ctx.variant = causal, variant

@@ -27,10 +27,10 @@ class _FlashAttnBNHD(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, causal, softmax_scale=None):
-        # one scale-guard pass over q, k serves the forward and the backward (none needed when the caller folded the scale: the
-        # kernels' factor is then exactly 1)
-        guard = None if softmax_scale is not None else device_ops._auto_guard(q, k, None, "auto")
-        o, l, _ = device_ops.flash_attn_fwd_bnhd(q, k, v, causal, _lib.FA_VARIANT_FA2, softmax_scale, guard=guard)
+        # the forward fills the scale guard inside its own launch, the backward reads it (none needed when the caller folded the
+        # scale: the kernels' factor is then exactly 1)
+        guard = None if softmax_scale is not None else device_ops.new_guard(q)
+        o, l, _ = device_ops.flash_attn_fwd_bnhd(q, k, v, causal, _lib.FA_VARIANT_FA2, softmax_scale, guard=guard, produce_guard=True)
         none = torch.empty(0, device=q.device)
         ctx.save_for_backward(q, k, v, o, l, guard if guard is not None else none)
         ctx.causal, ctx.softmax_scale = causal, softmax_scale
@@ -49,8 +49,8 @@ class _FlashAttnBHND(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, causal):
-        guard = device_ops._auto_guard(q, k, None, "auto")
-        o, l, _ = device_ops.flash_attn_fwd(q, k, v, causal, _lib.FA_VARIANT_FA2, guard=guard)
+        guard = device_ops.new_guard(q)
+        o, l, _ = device_ops.flash_attn_fwd(q, k, v, causal, _lib.FA_VARIANT_FA2, guard=guard, produce_guard=True)
         none = torch.empty(0, device=q.device)
         ctx.save_for_backward(q, k, v, o, l, guard if guard is not None else none)
         ctx.causal = causal

@@ -177,12 +177,18 @@ int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* o
  *                           returns at once: no host synchronisation, about 4 us per skipped launch.  guard = NULL, or any other
  *                           entry point of this header: fp32 scaling (opts[8] = 1 overrides).  The forward and the backward of one
  *                           q / k pair take the same guard (compute it once).  softmax_scale = 0: sqrt(1/d).
+ *   produce_guard = 1       (forward only, opts[8] = 0) the call FILLS `guard` instead of reading it, for the backward of the same
+ *                           (q, k): a forward that folds forms the row norms inside its own launch (every wave holds its 32 query
+ *                           rows anyway and loads the 32 key rows of the same indices; atomic maxima into the zero-filled guard) and
+ *                           runs optimistically; its fp32-scaling twin, launched behind it, redoes the call if the finished guard says
+ *                           so.  No separate pass over q and k: the forward costs one 2-KiB memset and the twin's empty launch.  A
+ *                           forward that folds nothing runs fa_mi355x_scale_guard itself (the backward of the call may fold).
  * A caller that folds log2(e)/sqrt(d) into its query projection and passes softmax_scale = ln(2) needs no guard: the factor is 1. */
 size_t fa_mi355x_guard_bytes(void);
 int fa_mi355x_scale_guard(const void* q, const void* k, long rows, int row_elems, int dtype, void* guard, void* stream);
 int fa_mi355x_fwd_guarded(const void* q, const void* k, const void* v, float* out, float* l, float* m, int B, int H, int N, int d,
                           int layout, float softmax_scale, int causal, int variant, int dtype, const int* opts, int nopts,
-                          const void* guard, void* stream);
+                          void* guard, int produce_guard, void* stream);
 int fa_mi355x_bwd_guarded(const void* q, const void* k, const void* v, const float* out, const void* out_grad, float* q_grad,
                           float* k_grad, float* v_grad, const float* l, const float* m, void* workspace, int B, int H, int N, int d,
                           int layout, float softmax_scale, int causal, int variant, int dtype, int stages, const int* opts,

@@ -521,6 +521,14 @@ def test_scale_guard_routes_by_operand_size_without_a_host_sync(dev, causal, d):
 
         default = run(None, "auto")
         shared = run(None, guard)                       # one guard pass for forward and backward
+        # ... and without any separate pass: the forward FILLS a guard inside its own launch (optimistically, redone by its twin when
+        # beyond the budget) and the backward reads it; the maxima it leaves are those of the separate pass
+        g2 = dev.new_guard(t[0])
+        o_, L_, _ = dev.flash_attn_fwd(*t[:3], causal, guard=g2, produce_guard=True)
+        gr = dev.flash_attn_bwd(*t[:3], o_, t[3], L_, None, causal, guard=g2)
+        produced = [to_np(x) for x in (o_, L_) + tuple(gr)]
+        assert abs(float(g2[:256].max()) - gq) < 1e-5 * gq and abs(float(g2[256:].max()) - gk) < 1e-5 * gk
+        assert all(np.array_equal(a, b) for a, b in zip(produced, default))
         folded = run(dev.OPTS_FOLDED_SCALE, None)
         exact = run(dev.OPTS_EXACT_SCALE, None)
         same = exact if want_exact else folded

@@ -43,9 +43,9 @@ def test_plan_matches_what_bench_times(shape, fwd_names, bwd_names):
         assert gb[:2] == bwd_names and set(gb[2:]) == {"bwd_dq_kernel", "bwd_dkdv_kernel"}
     else:
         assert gb == bwd_names
-    stages, k_fwd, k_dq, k_dkdv = bench.stage_plan(device_ops, BH, N, d, causal, dtype, None, lambda: None, lambda s=7: None, lambda: None)
-    # the guard pass first; no preprocess kernel: the dQ launch does it and runs before dK/dV
-    assert [n for n, _ in stages] == ["scale_guard_kernel"] + fwd_names + bwd_names
+    stages, k_fwd, k_dq, k_dkdv = bench.stage_plan(device_ops, BH, N, d, causal, dtype, None, lambda: None, lambda s=7: None, True)
+    # no guard pass (the forward's launch fills the guard) and no preprocess kernel (the dQ launch does it and runs before dK/dV)
+    assert [n for n, _ in stages] == fwd_names + bwd_names
     assert (k_fwd, k_dq, k_dkdv) == (fwd_names[0], bwd_names[0], bwd_names[1])
     # stage-split calls name the same kernels (plus the preprocess kernel when dQ is not in the call)
     assert _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_DKDV, fold) == [bwd_names[1]]
