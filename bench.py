@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--opts", type=str, default="", help="comma-separated per-call kernel options (fa_mi355x_*_ex), A/B runs only")
     ap.add_argument("--out-bf16", action="store_true",
                     help="--config c4: the forward stores O as bf16 (one rounding of the fp32 result), so the gather moves 256 MiB per rank")
+    ap.add_argument("--amp", type=float, default=1.0,
+                    help="A/B runs only: q and k are drawn from U(-amp, amp) (the metric's domain is amp = 1; amp >= 1.3 sends the "
+                         "guarded default to its fp32-scaling kernels)")
     ap.add_argument("--phased", action="store_true",
                     help="profiling A/B only: run the phased (round-1 v5) kernels instead of the MFMA-slot ones")
     return ap.parse_args()
@@ -365,6 +368,8 @@ def main():
     gen = torch.Generator(device="cuda").manual_seed(1004 + rank)
     mk = lambda: ((torch.rand((BH, N, d), device="cuda", generator=gen) - 0.5) * 2).to(tdt)  # U(-1,1), test_utils.py:104
     q, k, v, do = mk(), mk(), mk(), mk()
+    if args.amp != 1.0:
+        q, k = (q.float() * args.amp).to(tdt), (k.float() * args.amp).to(tdt)
     out = torch.empty((BH, N, d), dtype=torch.float32, device="cuda")
     L = torch.empty((BH, N), dtype=torch.float32, device="cuda")
     grads = tuple(torch.empty((BH, N, d), dtype=torch.float32, device="cuda") for _ in range(3))

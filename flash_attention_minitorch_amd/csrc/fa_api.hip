@@ -68,6 +68,8 @@ void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> 
     t_fold = true;                                                          \
     FA_LAUNCH(kern, grid, block, shmem, st, __VA_ARGS__);                   \
   } while (0)
+// ... of a backward MFMA-slot kernel that carries BOTH scalings and picks one per launch (Layout::scale_sel): no twin needed
+#define FA_LAUNCH_SEL(kern, grid, block, shmem, st, ...) FA_LAUNCH(kern, grid, block, shmem, st, __VA_ARGS__)
 // ... and can fill the call's scale guard inside its own launch (the non-causal builds of the slot forward: guard_produce)
 #define FA_LAUNCH_FOLD_P(kern, grid, block, shmem, st, ...)                 \
   do {                                                                      \
@@ -417,7 +419,7 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
   if (DIAG == 0 && causal && N % 256 == 0) {   // causal build: unmasked sweep + the diagonal block per wave; one block per workgroup,
     // longest first across all heads (paired: blocks p and nqb-1-p in one workgroup)
     const dim3 grid(paired ? batch * ((nqb + 1) / 2) : batch * nqb);
-    FA_LAUNCH_FOLD((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
+    FA_LAUNCH_SEL((fa::bwd_dq_slot_kernel<T, D, 0, false, true>), grid, dim3(512), 0, st, (const T*)q, (const T*)k,
               (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, paired ? 1 : 2, tau, prep ? *prep : fa::DqPrep{});
   } else if (DIAG == 0 && !causal && N % 128 == 0) {   // no sub-tile needs a mask: the build without masked period variants
     // Query block qb of several consecutive heads per workgroup (the tiled build: no set-up, no wait for the first stage, no store
@@ -430,10 +432,10 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
     }
     if (tiles > 1) {
       lay.tiles = tiles;
-      FA_LAUNCH_FOLD((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3((batch / tiles) * nqb), dim3(512), 0, st, (const T*)q,
+      FA_LAUNCH_SEL((fa::bwd_dq_slot_kernel<T, D, 0, false, false, true>), dim3((batch / tiles) * nqb), dim3(512), 0, st, (const T*)q,
                 (const T*)k, (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, prep ? *prep : fa::DqPrep{});
     } else {
-      FA_LAUNCH_FOLD((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
+      FA_LAUNCH_SEL((fa::bwd_dq_slot_kernel<T, D, 0, false>), dim3(batch * nqb), dim3(512), 0, st, (const T*)q, (const T*)k,
                 (const T*)v, (const T*)dout, nlc, delta, dq, N, nqb, batch, lay, causal, tau, prep ? *prep : fa::DqPrep{});
     }
   } else {
@@ -653,7 +655,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         rc = dkdv_launch<T, D, 32, 8, 128, 9>(q, k, v, dout, nlc, delta, dk, dv, batch, N, lay, causal, tau, st);
       else if (D == 64 && !causal && tun.v[0] == 193 && !lay.drop_thr) {   // continuous slot pipeline with phase stamps
         const int nkb = (N + 255) / 256;
-        FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 1>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
@@ -673,10 +675,10 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         }
         if (tiles > 1) {
           lay.tiles = tiles;
-          FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
+          FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 0, false, true>), dim3((batch / tiles) * nkb), dim3(512), 0, st,
                              (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         } else {
-          FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+          FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 0>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                              (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         }
         FA_HIP_TRY(hipGetLastError());
@@ -687,7 +689,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // diagonal block, the block per wave, workgroups longest first); tuning key 0 = 3: the phased kernel below
         const int nkb = N / 256;
         lay.rank_chunk = rank_chunk(1, nkb);
-        FA_LAUNCH_FOLD((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+        FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
                            (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
@@ -779,14 +781,13 @@ fa::Layout bnhd(int H, int N, int dp) { return fa::Layout{H, H * dp, (long)N * H
 //     selected kernels AND their fp32-scaling twins; every workgroup evaluates the guard on entry and the launch on the wrong side of
 //     the budget returns at once (fa_common.h: guard_skip).  Estimate: 2^-9 / sqrt(3) * c * max_rows |q| * max_rows |k| against
 //     GUARD_BUDGET (log2 units): U(-1, 1) gives 5.7e-3 at d = 64 and 7e-3 at d = 128, inputs 1.3x larger go to fp32 scaling.
-//   * a call WITHOUT one runs the fp32-scaling kernels (options 0 / 1 / 2 at 4 / 2 / 2), unless
+//   * a call WITHOUT one scales in fp32 (the phased forward; the backward's slot kernels carry both scalings in one launch and
+//     take their fp32 copy of the sweep: no twin launches in the backward at all), unless
 //     option 8 = 1 (the caller vouches for the range), the selection folds nothing anyway (fp32, d = 32, key mask, dropout, ragged N:
 //     probed with a dry run of the dispatch code), or c is 1 (softmax_scale = ln 2: the operand multiply is exact).
 constexpr float GUARD_BUDGET = 1e-2f;
-inline Tun exact_tun(Tun t) {   // the kernels that scale every score in fp32 (the phased builds), whatever else the caller selected
-  t.v[0] = 4;
+inline Tun exact_tun(Tun t) {   // the forward that scales every score in fp32 (the phased kernel), whatever else the caller selected
   t.v[1] = 2;
-  t.v[2] = 2;
   return t;
 }
 // produce (forward calls only, option 8 = 0): the call FILLS `guard` instead of reading it, so that the backward of the same (q, k)
@@ -797,8 +798,16 @@ template <class F, class Z, class G>
 int run_scaled(F&& run, const Tun& tun, fa::Layout lay, float tau, const float* guard, int produce, Z&& zero_guard, G&& guard_pass) {
   const float c = tau * fa::LOG2E;
   const int mode = tun.v[8];
+  lay.scale_sel = 0;
   if (mode == 1 || fabsf(c - 1.0f) < 1e-6f) return run(tun, lay);
   if (mode == 3 && t_plan) guard = reinterpret_cast<const float*>(16);   // fa_mi355x_plan: both launches of a guarded call
+  // the backward's MFMA-slot kernels hold both scalings in one launch: fp32 scaling without a guard, the guard's choice with one
+  lay.scale_sel = (mode == 2 || !guard) ? 1 : 2;
+  if (lay.scale_sel == 2) {
+    lay.guard = guard;
+    lay.guard_coef = c * (0.001953125f * 0.57735027f) / GUARD_BUDGET;
+    lay.guard_want = 3;   // (no launch of this run is skipped)
+  }
   if (!plan_mode() || t_plan) {   // does the selection fold at all?  (dry run: no launch, no HIP call, nothing recorded)
     std::vector<std::string>* keep = t_plan;
     t_plan = nullptr;

@@ -321,6 +321,11 @@ struct Layout {
   float guard_coef;      // the operand-rounding estimate in units of its budget is guard_coef * sqrt(max |q|^2 * max |k|^2)
   int guard_want;
   int out_bf16;          // forward kernels: `o` points to bf16 elements (same shape and row stride), rounded once from the fp32 result
+  // Backward MFMA-slot kernels (bwd_dq_slot_kernel's mask-free builds, bwd_dkdv_slot_kernel): both scalings live in ONE launch, chosen
+  // per launch by a wave-uniform branch around two copies of the sweep: 0 = tau*log2(e) folded into the bf16 operand (P = exp2(S')),
+  // 1 = the operand stays unscaled and every score is multiplied in fp32 (P = exp2(c * S'), the reference's arithmetic), 2 = by the
+  // scale guard (fa_common.h: scale_exact).  The forward keeps the pair-of-launches form (its fp32-scaling twin is another kernel).
+  int scale_sel;
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two

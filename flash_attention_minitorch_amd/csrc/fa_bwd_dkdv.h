@@ -654,7 +654,11 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   rsrc_t krs = make_rsrc(k + base, mat_bytes);
   rsrc_t vrs = make_rsrc(v + base, mat_bytes);
   raw_rsrc_t qraw = make_raw_rsrc(q + base, mat_bytes), doraw = make_raw_rsrc(dout + base, mat_bytes);
-  raw_rsrc_t nlraw = make_raw_rsrc(nl2 + (size_t)bh * N, (uint32_t)N * 4u);
+  // Both scalings in one launch (Layout::scale_sel): exact = the K fragments stay unscaled, the row constant is -L/tau (raw score
+  // units: the workspace's FIRST vector, two vectors in front of nl2) and every score is multiplied in fp32, P = exp2(c * S').
+  const bool exact = scale_exact(lay);   // wave-uniform
+  const float* nlv = exact ? nl2 - 2 * (size_t)BH * N : nl2;
+  raw_rsrc_t nlraw = make_raw_rsrc(nlv + (size_t)bh * N, (uint32_t)N * 4u);
   raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
   const float c = tau * LOG2E;
   const int kw0 = kb * BK + w * KPW;
@@ -671,6 +675,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   };
   load_kv(kw0);
   auto scale_k = [&]() {   // (called where the fragments are first needed: scaling them forces the wait for their loads)
+    if (exact) return;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) kf[kc] = A::scale(kf[kc], c);
   };
@@ -724,6 +729,9 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
+  // (two copies of the sweep, one per scaling: the fp32 multiply of the exact one exists in its own instruction stream only)
+  auto sweep = [&](auto ex_c) {
+  constexpr bool EX = decltype(ex_c)::value != 0;
   if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
   f32x16 sA, dpA, sB, dpB, cS, cD;
   frag pf0, pf1, df0, df1, rq[4], rdo[4], tf[4];
@@ -746,7 +754,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
       for (int j = 0; j < 4; ++j) x[4 * g + j] = a[j];
     }
   };
-  auto me = [&](f32x16& x, int i) { x[i] = __builtin_amdgcn_exp2f(x[i]); };
+  auto me = [&](f32x16& x, int i) { x[i] = EX ? __builtin_amdgcn_exp2f(x[i] * c) : __builtin_amdgcn_exp2f(x[i]); };
   // One period.  SN: sub-slice whose S', dP' are produced, rows at (nr0, nr1) [its dO rows 1..3 are requested here]; SC:
   // sub-slice in the softmax / dV, dK stream, transposed reads at (ct0, ct1); SP: the sub-slice after SN, whose Q rows, row
   // constants and first dO row are requested in slots 12-15 at (pr0, pr1, ph16).
@@ -866,7 +874,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
       const size_t nbase = head_base(lay, bh + 1);
       qraw = make_raw_rsrc(q + nbase, mat_bytes);
       doraw = make_raw_rsrc(dout + nbase, mat_bytes);
-      nlraw = make_raw_rsrc(nl2 + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
+      nlraw = make_raw_rsrc(nlv + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
       ndraw = make_raw_rsrc(ndelta + (size_t)(bh + 1) * N, (uint32_t)N * 4u);
       stage_dma(0, nb);
     }
@@ -916,6 +924,9 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     }
   }
   }   // heads of this workgroup
+  };
+  if (exact) sweep(ic<1>{});
+  else sweep(ic<0>{});
   if constexpr (TILED) return;
   }
   if constexpr (CDIAG) {
@@ -961,8 +972,13 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
             A::mma(dp, ado, vf[kc]);
           }
         }
+        if (exact) {   // (the staged row constant is -L/tau then)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nl16[i]));
+          for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f((s[i] + nl16[i]) * c);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, nl16[i]));
+        }
       } else {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -976,8 +992,13 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
             A::mma(dp, ado, vf[kc]);
           }
         }
+        if (exact) {   // (unscaled K, row constant in raw units)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+          for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] * c);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+        }
       }
       if (j == w) {   // this wave's own 32 queries: key kw0 + r against query qi0 + row
 #pragma unroll

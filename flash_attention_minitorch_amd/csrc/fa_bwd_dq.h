@@ -359,7 +359,10 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   // than 64 admissible keys (causal build, query block 0: no sweep, only the diagonal block) keep the unscaled Q and the fp32 fma.
   constexpr bool PRE = !MASKS;
   const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform
-  if (PRE && !exactq) {
+  // Both scalings in one launch (Layout::scale_sel; the mask-free builds): exact = the Q fragments stay unscaled, -L/tau (raw score
+  // units) enters S^T as the accumulator input and every score is multiplied in fp32, P = exp2(c * S').
+  const bool exact = PRE && scale_exact(lay);   // wave-uniform
+  if (PRE && !exactq && !exact) {
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) qf[kc] = A::scale(qf[kc], c);
   }
@@ -370,7 +373,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     nd16[i] = NDACC ? ndq : 0.f;
-    nl16[i] = PRE ? nlq : 0.f;
+    nl16[i] = PRE ? (exact ? nlq * (1.0f / c) : nlq) : 0.f;
   }
   f32x16 acc[2];
   acc[0] = zero16();
@@ -420,6 +423,9 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
   if (lay.young_prio && w >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses VALU arbitration otherwise
+  // (the mask-free builds carry two copies of the sweep, one per scaling: the fp32 multiply exists in the exact one's stream only)
+  auto sweep = [&](auto ex_c) {
+  constexpr bool EX = decltype(ex_c)::value != 0;
   // sub-tile state: A / B alternate between "being produced" and "being consumed"
   f32x16 sA, dpA, sB, dpB;
   frag dsA0, dsA1, dsB0, dsB1;   // packed dS^T of the sub-tile before the current one / of the current one
@@ -449,7 +455,8 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     float cm = c;
     if constexpr (MASK) asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the masked and unmasked variants' common fma
     auto fe = [&](int i) {
-      float pv = PRE ? __builtin_amdgcn_exp2f(cs[i]) : __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nlq));
+      float pv = PRE ? (EX ? __builtin_amdgcn_exp2f(cs[i] * c) : __builtin_amdgcn_exp2f(cs[i]))
+                     : __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nlq));
       if constexpr (MASK) pv = (acc_row(i, h) > klim) ? 0.f : pv;
       cs[i] = pv;
     };
@@ -597,6 +604,14 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   }
   // drain: dQ of the last sub-tile (sub 3 of the last stage); the "produced" sub-tile of the last period is unused
   period(T0, T0, T1, T0, ic<0>{}, ic<3>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, 0, sB, dpB, sA, dpA, dsB0, dsB1, dsA0, dsA1);
+  };
+  if constexpr (PRE) {
+    if (exact) sweep(ic<1>{});
+    else sweep(ic<0>{});
+  } else {
+    sweep(ic<0>{});
+  }
+  auto slot_of = [&](int st) { return ((st + roff) % 3) * TB; };   // (as inside the sweep)
   if constexpr (TILED) roff = (roff + nstage) % 3;
   if constexpr (CDIAG) {   // the stage hand-off this wave has no periods for (same DMA share, wait and barrier as in the loop)
     for (int st = nst_w; st < nst_all; ++st) {
@@ -612,7 +627,7 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     // requested and published by the hand-offs above.  Left for the plain per-sub-tile form: sub-tiles 0..w (waves 0-3), 4..w
     // (waves 4-7, which swept the block's first stage): at most four per wave instead of up to eight.
     const bool careful = exactq;   // wave-uniform
-    const float cmd = exactq ? c : 1.0f;   // (the other waves' scores leave the MFMA chain in log2 units)
+    const float cmd = (exactq || exact) ? c : 1.0f;   // (the other waves' scores leave the MFMA chain in log2 units)
     for (int j = 4 * (w >> 2); j <= w; ++j) {
       const int sb = ((nstage + (j >> 2)) % 3) * TB;
       lds_char* tk = smem + sb;

@@ -50,8 +50,7 @@ template <> FA_DEV f32x8 load_frag_buf<float>(rsrc_t rs, int byte_off) {
 // once unless the estimate for the call's largest rows is on its side of the budget (Layout::guard_want: 0 = within, 1 = beyond).
 // Everything is wave-uniform after the reduction; a launch without a guard (Layout::guard == nullptr) pays one scalar branch.
 constexpr int GUARD_SLOTS = 256;
-FA_DEV bool guard_skip(const Layout& L) {
-  if (L.guard == nullptr || L.guard_want == 2) return false;   // (2: this launch PRODUCES the guard, see guard_produce)
+FA_DEV bool guard_beyond(const Layout& L) {   // the call's operands are beyond the folded scale's budget (wave-uniform)
   const int lane = threadIdx.x & 63;
   const f32x4 a = *reinterpret_cast<const f32x4*>(L.guard + 4 * lane);
   const f32x4 b = *reinterpret_cast<const f32x4*>(L.guard + GUARD_SLOTS + 4 * lane);
@@ -62,7 +61,17 @@ FA_DEV bool guard_skip(const Layout& L) {
     km = fmaxf(km, __shfl_xor(km, off));
   }
   const bool beyond = !(L.guard_coef * __builtin_sqrtf(qm * km) <= 1.0f);   // (NaN / Inf inputs count as beyond)
-  return __builtin_amdgcn_readfirstlane((int)beyond) != (L.guard_want != 0);
+  return __builtin_amdgcn_readfirstlane((int)beyond) != 0;
+}
+FA_DEV bool guard_skip(const Layout& L) {
+  // (want 2: this launch PRODUCES the guard, see guard_produce; want 3: it takes both sides itself, see scale_exact)
+  if (L.guard == nullptr || L.guard_want >= 2) return false;
+  return guard_beyond(L) != (L.guard_want != 0);
+}
+// The backward slot kernels: which copy of the sweep does this launch run?  (Layout::scale_sel)
+FA_DEV bool scale_exact(const Layout& L) {
+  if (L.scale_sel != 2 || L.guard == nullptr) return L.scale_sel != 0;
+  return guard_beyond(L);
 }
 
 // The forward can produce the guard itself instead of a separate pass over q and k (Layout::guard_want == 2, a zero-filled guard):
@@ -71,7 +80,11 @@ FA_DEV bool guard_skip(const Layout& L) {
 // wave's largest squared row norms go to slot (blockIdx & 255) with an atomic max on the float bits (non-negative floats order like
 // unsigned integers; a NaN row reads as "beyond the budget").  Optimistic: the launch itself runs with the folded scale, and its
 // fp32-scaling twin, launched behind it, redoes the call if the finished guard says so.  qs / ks: the lane's half-row sums of squares.
-FA_DEV void guard_produce(const Layout& L, float qs, float ks) {
+// (512-thread workgroups: eight waves.)
+// Returns true when the WORKGROUP's own rows (scratch: 64 bytes of its LDS, two barriers) are already beyond the budget: the call's
+// maxima can only be larger, the twin will redo the call, and the whole workgroup leaves at once instead of sweeping for nothing
+// (operands that are large throughout, the usual case, cost the optimistic launch a few microseconds, not a forward).
+FA_DEV bool guard_produce(const Layout& L, float qs, float ks, lds_char* scratch) {
   qs = xhalf_sum(qs);
   ks = xhalf_sum(ks);
 #pragma unroll
@@ -79,11 +92,23 @@ FA_DEV void guard_produce(const Layout& L, float qs, float ks) {
     qs = fmaxf(qs, __shfl_xor(qs, off));
     ks = fmaxf(ks, __shfl_xor(ks, off));
   }
+  const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     unsigned* g = reinterpret_cast<unsigned*>(const_cast<float*>(L.guard)) + (blockIdx.x & (GUARD_SLOTS - 1));
     atomicMax(g, __float_as_uint(qs));
     atomicMax(g + GUARD_SLOTS, __float_as_uint(ks));
+    *FA_LDS(float, scratch + 4 * w) = qs;
+    *FA_LDS(float, scratch + 32 + 4 * w) = ks;
   }
+  __syncthreads();
+  float qm = 0.f, km = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    qm = fmaxf(qm, *FA_LDS(float, scratch + 4 * i));
+    km = fmaxf(km, *FA_LDS(float, scratch + 32 + 4 * i));
+  }
+  __syncthreads();   // (the scratch is the head of the first K stage: its LDS-DMA follows)
+  return !(L.guard_coef * __builtin_sqrtf(qm * km) <= 1.0f);
 }
 template <typename F> FA_DEV float frag_sumsq(const F& f) {
   float s = 0.f;

@@ -452,7 +452,7 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       qs += frag_sumsq(qf[kc]);
       ks += frag_sumsq(load_frag_buf<T>(krs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T)));
     }
-    guard_produce(lay, qs, ks);
+    if (guard_produce(lay, qs, ks, smem)) return;   // (workgroup-uniform)
   }
   const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform: rows with fewer than 64 admissible keys (query block 0 only)
   if (PRE && !exactq) {

@@ -39,10 +39,8 @@ def test_plan_matches_what_bench_times(shape, fwd_names, bwd_names):
     guarded = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, 0, bench.with_scale_mode(None, 3))
     assert guarded == fwd_names + exact_fwd
     gb = _lib.plan(BH, N, d, causal, _lib.FA_VARIANT_FA2, dt, device_ops.STAGE_ALL, bench.with_scale_mode(None, 3))
-    if d == 64:     # (d = 128: the backward kernels scale in fp32 anyway: one launch each)
-        assert gb[:2] == bwd_names and set(gb[2:]) == {"bwd_dq_kernel", "bwd_dkdv_kernel"}
-    else:
-        assert gb == bwd_names
+    # (the backward needs no twins: its d = 64 slot kernels carry both scalings in one launch, the d = 128 kernels scale in fp32)
+    assert gb == bwd_names
     stages, k_fwd, k_dq, k_dkdv = bench.stage_plan(device_ops, BH, N, d, causal, dtype, None, lambda: None, lambda s=7: None, True)
     # no guard pass (the forward's launch fills the guard) and no preprocess kernel (the dQ launch does it and runs before dK/dV)
     assert [n for n, _ in stages] == fwd_names + bwd_names
@@ -57,7 +55,8 @@ def test_plan_of_option_and_feature_paths():
     bf, fa2 = _lib.FA_DTYPE_BF16, _lib.FA_VARIANT_FA2
     # the phased kernels (fp32 scaling) on request
     assert _lib.plan(64, 4096, 64, False, fa2, bf, 0, device_ops.OPTS_EXACT_SCALE) == ["fwd_kernel"]
-    assert _lib.plan(64, 4096, 64, False, fa2, bf, 7, device_ops.OPTS_EXACT_SCALE) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
+    assert _lib.plan(64, 4096, 64, False, fa2, bf, 7, device_ops.OPTS_EXACT_SCALE) == ["bwd_dq_slot_kernel", "bwd_dkdv_slot_kernel"]   # (their fp32-scaling sweep)
+    assert _lib.plan(64, 4096, 64, False, fa2, bf, 7, device_ops.OPTS_PHASED) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
     # a ragged causal launch: phased kernels, each followed by its split-operand launch for the rows with few keys
     assert _lib.plan(2, 200, 128, True, fa2, bf, 0) == ["fwd_kernel", "fwd_kernel"]
     # fp32 (the reference's own dtype)
