@@ -135,7 +135,14 @@ inline size_t fused_extra_bytes(int batch, int N, int d) {
 #else
 inline size_t fused_extra_bytes(int, int, int) { return 0; }   // the product library runs the two-kernel backward only
 #endif
-int device_cus() {   // compute units of the current device (cached per device; any thread)
+int device_cus_raw();
+// Compute units the launch-size rules assume: the current device's, or 256 (an MI355X) when there is none -- fa_mi355x_plan without a
+// GPU must name the kernels a real launch would select (three rules used max(cus, 1) and two `cus > 0 ? cus : 256`).
+int device_cus() {
+  const int n = device_cus_raw();
+  return n > 0 ? n : 256;
+}
+int device_cus_raw() {   // compute units of the current device (cached per device; any thread); 0 without one
   static std::mutex mu;
   static int cus[64];
   int dev = 0;

@@ -544,6 +544,10 @@ bwd_dq_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
   int ct0 = ta.b[0] + b0_, ct1 = ta.b[1] + b0_;     // transposed reads of the current stage
   int pt0 = ct0, pt1 = ct1;                         // ... of the previous stage (stage 0: any finite data, dS = 0)
   // prologue: rows of sub-tile 0, then S^T(0), dP^T(0)
+  // (causal build, ADVICE r3: a wave with no stage to sweep -- waves 0-3 of query block 0 -- runs neither the prologue nor the drain
+  // period: the drain would multiply dS = 0 into K rows beyond the wave's causal horizon, and 0 * Inf there is NaN where the reference,
+  // which never touches those rows, is finite)
+  if (CDIAG && nst_w == 0) return;
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) rk[kc] = krow(cr0, cr1, 0, kc);
   dsB0 = A::zero();

@@ -728,6 +728,15 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   }
   // drain: P.V of the last sub-tile (the buffers alternate per sub-tile: an even count per stage ends on B)
   period(T0, T0, T1, T0, ic<0>{}, ic<NSUBT - 1>{}, ic<0>{}, ic<0>{}, cr0, cr1, pt0, pt1, cr0, cr1, cr0, cr1, 0, sB, sA, pB0, pB1, pA0, pA1);
+  if constexpr (CDIAG) {
+    // (a wave with no stage to sweep -- the first two of query block 0 -- has just multiplied P = 0 into V rows beyond its
+    // causal horizon: 0 * Inf there is NaN where the reference, which never touches those rows, is finite.  Its accumulators hold
+    // nothing yet: cleared here.  Skipping the two periods instead cost the build, which sits at 128 registers, 152 B of scratch.)
+    if (nst_w == 0) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc_o[dt] = zero16();
+    }
+  }
   if constexpr (CDIAG) {   // the stage hand-offs this wave has no periods for (same DMA share, wait and barrier as in the loop)
     for (int st = nst_w; st < nst_all; ++st) {
       if (st > 0) {

@@ -151,8 +151,9 @@ def flash_attn_fwd(q, k, v, causal=False, variant=_lib.FA_VARIANT_FA2, out=None,
     bh, n, d = _check_inputs(q, k, v)
     lead = q.shape[:-2]
     if d not in _NATIVE_D:
-        if out_dtype != torch.float32:
-            raise ValueError("a bf16 output needs a native head dim (32, 64, 128)")
+        if out_dtype != torch.float32 or opts is not None:
+            raise ValueError("per-call options and a bf16 output need a native head dim (32, 64, 128): other d run zero-padded through "
+                             "fa_mi355x_fwd_padded, which takes neither")
         dp = _padded_d(d)
         qp, kp, vp = (_pad_cols(t, dp) for t in (q, k, v))
         outp = torch.empty(lead + (n, dp), dtype=torch.float32, device=q.device)
@@ -225,6 +226,9 @@ def flash_attn_bwd(q, k, v, out, out_grad, l, m=None, causal=False, variant=_lib
     if out.dtype != torch.float32 or out.shape != q.shape or not out.is_contiguous():
         raise ValueError("out must be the forward's contiguous float32 output")
     if d not in _NATIVE_D:   # any d <= 128: zero-padded columns, see flash_attn_fwd
+        if opts is not None or stages != STAGE_ALL or workspace is not None:
+            raise ValueError("per-call options, a stage mask and a caller's workspace need a native head dim (32, 64, 128): other d run "
+                             "zero-padded through fa_mi355x_bwd_padded, which takes none of them")
         dp = _padded_d(d)
         qp, kp, vp, op, dop = (_pad_cols(t, dp) for t in (q, k, v, out, out_grad))
         ws = _workspace(bh, n, dp, q.device)

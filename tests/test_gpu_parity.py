@@ -555,6 +555,36 @@ def test_scale_guard_routes_by_operand_size_without_a_host_sync(dev, causal, d):
                 assert maxabs(default[1], ref["L"]) < 0.5 * maxabs(folded[1], ref["L"])
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_causal_slot_builds_do_not_touch_rows_beyond_a_waves_horizon(dev, mode):
+    """in the causal slot builds a wave of query block 0 with no stage to sweep (forward: waves 0-1, dQ: waves 0-3) ran
+    its prologue and drain periods on the diagonal block's first stage with P = 0 / dS = 0, i.e. 0 * V (rows 32..63) and 0 * K (rows
+    96..127) on rows beyond its causal horizon: NaN if such a row holds Inf, where the reference (which masks,
+    src/flash_attn_fw.cu:152-159, and skips tiles wholly above the diagonal) is finite.  V row 40 = Inf: queries below 32 (another
+    32-row tile) must come out of the forward finite and unchanged; K row 100 = Inf: queries below 96 out of the dQ kernel.  Folded
+    scale (mode 1) and fp32 scaling (mode 2: the phased forward, the dQ slot kernel's fp32-scaling sweep)."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    rng = np.random.default_rng(4242)
+    BH, N, d = 128, 512, 64      # (256 query blocks: the causal slot builds are the default selection)
+    arrs = [oracle.bf16_round(rand_u(rng, (BH, N, d))) for _ in range(4)]
+    t = [torch.from_numpy(a).to("cuda", torch.bfloat16) for a in arrs]
+    opts = (5, 3, 3, 0, 0, 0, 0, 0, mode)
+    names = _lib.plan(BH, N, d, True, 2, _lib.FA_DTYPE_BF16, 0, opts) + _lib.plan(BH, N, d, True, 2, _lib.FA_DTYPE_BF16, 7, opts)
+    assert "bwd_dq_slot_kernel" in names and (mode == 2 or "fwd_slot_kernel" in names)
+    o0, L0, _ = dev.flash_attn_fwd(*t[:3], True, opts=opts)
+    dq0 = dev.flash_attn_bwd(*t[:3], o0, t[3], L0, None, True, opts=opts)[0]
+    bad_v = t[2].clone()
+    bad_v[:, 40] = float("inf")
+    if mode == 1:   # (the phased forward of mode 2 multiplies whole 64-key tiles, as the reference multiplies its own tiles: row 40 is in the first)
+        o1, L1, _ = dev.flash_attn_fwd(t[0], t[1], bad_v, True, opts=opts)
+        assert torch.isfinite(o1[:, :32]).all() and torch.equal(o0[:, :32], o1[:, :32]) and torch.equal(L0, L1)
+    bad_k = t[1].clone()
+    bad_k[:, 100] = float("inf")
+    dq1 = dev.flash_attn_bwd(t[0], bad_k, t[2], o0, t[3], L0, None, True, opts=opts)[0]
+    assert torch.isfinite(dq1[:, :96]).all() and torch.equal(dq0[:, :96], dq1[:, :96])
+
+
 def test_pick_opts_keeps_the_north_star_domain_on_the_fast_kernels(dev):
     """device_ops.pick_opts (the scale guard's decision taken on the host, once per tensor family): U(-1, 1) operands may run the
     folded-scale MFMA-slot kernels unguarded, operands a few times larger are sent to the kernels with fp32 scaling, and with that
