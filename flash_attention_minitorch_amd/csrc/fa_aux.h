@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) scale_guard_kernel(const bf16_t* __restri
   const bf16_t* p = blockIdx.y ? k : q;
   const long total = rows * LPR, stride = (long)gridDim.x * 256;
   float mx = 0.f;
-  constexpr int U = 4;
+  constexpr int U = 8;   // 16-byte loads in flight per lane: 16 MiB across the chip (4 gave 8 MiB = 4.6 TB/s at HBM latency)
   for (long c0 = (long)blockIdx.x * 256 + threadIdx.x; c0 < total; c0 += U * stride) {
     bf16x8 f[U];
 #pragma unroll

@@ -441,17 +441,23 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   int qrow = q0 + r;
 
   frag qf[KC];
+  // This launch produces the call's scale guard (fa_common.h: guard_produce): the key rows first, on their own, then the query rows,
+  // which stay.  Not the causal build: it sits at its 128 registers and spilled two to three around this in either order (causal
+  // calls take the separate guard pass).
+  const bool produce = PRE && !CDIAG && lay.guard_want == 2 && lay.guard != nullptr;
+  float ks = 0.f;
+  if (produce) {
+    const rsrc_t krs = make_rsrc(k + base, mat_bytes);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) ks += frag_sumsq(load_frag_buf<T>(krs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T)));
+    asm volatile("" : "+v"(ks));
+  }
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
-  // (not the causal build: it sits at its 128 registers and spilled two around this; causal calls take the separate guard pass)
-  if (PRE && !CDIAG && lay.guard_want == 2 && lay.guard != nullptr) {   // this launch produces the call's scale guard (fa_common.h: guard_produce)
-    const rsrc_t krs = make_rsrc(k + base, mat_bytes);
-    float qs = 0.f, ks = 0.f;
+  if (produce) {
+    float qs = 0.f;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      qs += frag_sumsq(qf[kc]);
-      ks += frag_sumsq(load_frag_buf<T>(krs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T)));
-    }
+    for (int kc = 0; kc < KC; ++kc) qs += frag_sumsq(qf[kc]);
     if (guard_produce(lay, qs, ks, smem)) return;   // (workgroup-uniform)
   }
   const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform: rows with fewer than 64 admissible keys (query block 0 only)

@@ -168,7 +168,7 @@ int fa_mi355x_bwd_ex(const void* q, const void* k, const void* v, const float* o
  * (MFMA-slot pipelines, d = 64 / 128) instead carry tau*log2(e) inside one bf16 MFMA operand, re-rounded once: exp2 then needs no
  * multiply per score (8-10 % of the step), at the price of one more 2^-9 relative rounding of q (or k).  That is invisible for inputs of
  * the reference tests' U(-1, 1) magnitude and grows with the square of the input magnitude, so those kernels run only on evidence:
- *   fa_mi355x_scale_guard   one pass over q and k (HBM-bound: 13 us at B=8, H=8, N=4096, d=64): the largest squared row norms, as
+ *   fa_mi355x_scale_guard   one pass over q and k (HBM-bound: 12 us at B=8, H=8, N=4096, d=64): the largest squared row norms, as
  *                           fa_mi355x_guard_bytes() bytes of device memory; rows = the number of rows of row_elems contiguous
  *                           elements (B*H*N rows of d in either layout; padded rows: dp).  fp32 or other row lengths: zero-filled.
  *   fa_mi355x_*_guarded     launch the selected kernels AND their fp32-scaling twins; every workgroup evaluates the guard on entry
