@@ -695,9 +695,27 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
         // d = 64, causal, N a multiple of 256: the causal build of the continuous pipeline (sweep of the stages below the
         // diagonal block, the block per wave, workgroups longest first); tuning key 0 = 3: the phased kernel below
         const int nkb = N / 256;
-        lay.rank_chunk = rank_chunk(1, nkb);
-        FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
-                           (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
+        // Round 4, DIAGNOSTIC BUILD ONLY (option 5 = 2; tools/check_causal_tiled.py): key blocks p and nkb-1-p of several consecutive
+        // heads per workgroup (the causal tiled build: uniform work, the ring carried from unit to unit).  Bitwise the ranked build and
+        // 4-8 % SLOWER (0.262 vs 0.251 ms at the metric shape, profiles/r04_causal_tiled_dkdv.txt), with 40 B of scratch: not kept.
+        int tiles = 0;
+#ifdef FA_DIAG
+        if (nkb % 2 == 0 && tun.v[5] == 2) {
+          const int cus = device_cus();
+          for (int t = 1; t <= 16; ++t)
+            if (batch % t == 0 && (batch / t) % 8 == 0 && (long)(batch / t) * (nkb / 2) >= cus) tiles = t;
+        }
+        if (tiles > 0) {
+          lay.tiles = tiles;
+          FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 0, true, true>), dim3((batch / tiles) * (nkb / 2)), dim3(512), 0, st,
+                        (const T*)q, (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
+        }
+#endif
+        if (tiles == 0) {
+          lay.rank_chunk = rank_chunk(1, nkb);
+          FA_LAUNCH_SEL((fa::bwd_dkdv_slot_kernel<T, 64, 0, true>), dim3(batch * nkb), dim3(512), 0, st, (const T*)q,
+                             (const T*)k, (const T*)v, (const T*)dout, nl2, delta, dk, dv, N, nkb, batch, lay, tau);
+        }
         FA_HIP_TRY(hipGetLastError());
         rc = FA_OK;
       } else if constexpr (D == 64) {   // d = 64, causal (or tuning 3): slot-interleaved fast path for unmasked stages, per-sub-slice path on the diagonal

@@ -642,12 +642,22 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   static_assert(!CDIAG || DIAG == 0, "causal build: no stamps");
   unsigned long long k_t00 = 0;
   if constexpr (DIAG) k_t00 = stamp();   // first instruction of the wave
-  static_assert(!TILED || (!CDIAG && DIAG == 0), "tiled build: non-causal, no stamps");
+  static_assert(!TILED || DIAG == 0, "tiled builds: no stamps");
+  // CT (round 4): the causal tiled build.  A workgroup takes key blocks p (heavy: it sweeps the most query stages) and nkb-1-p (light)
+  // of lay.tiles consecutive heads, one UNIT after the other, without leaving the ring: every workgroup does the same work (a pair
+  // sweeps nkb-1 blocks' worth of stages plus two diagonal blocks), so no ranking is needed; the first stage of the next unit is
+  // requested while the diagonal block of the current one is worked off, its K / V fragments before the dK / dV stores are issued.
+  constexpr bool CT = CDIAG && TILED;
   const int tiles = TILED ? max(lay.tiles, 1) : 1;   // heads per workgroup (the launcher sizes the grid with BH / tiles head groups)
   int bh, kb;   // (causal build: key block 0 sweeps the most query stages: the heaviest blocks of all heads are dispatched first)
-  if (CDIAG) map_block_ranked(blockIdx.x, BH, nkb, max(lay.rank_chunk, 1), bh, kb);
+  int pair = 0;
+  if (CT) {
+    map_block(blockIdx.x, BH / tiles, nkb / 2, bh, pair);   // (the launcher sends even nkb only)
+    kb = pair;
+  } else if (CDIAG) map_block_ranked(blockIdx.x, BH, nkb, max(lay.rank_chunk, 1), bh, kb);
   else map_block(blockIdx.x, BH / tiles, nkb, bh, kb);
   bh *= tiles;
+  const int nunits = CT ? 2 * tiles : 1;
   size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * (uint32_t)sizeof(T);
@@ -661,14 +671,20 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   raw_rsrc_t nlraw = make_raw_rsrc(nlv + (size_t)bh * N, (uint32_t)N * 4u);
   raw_rsrc_t ndraw = make_raw_rsrc(ndelta + (size_t)bh * N, (uint32_t)N * 4u);
   const float c = tau * LOG2E;
-  const int kw0 = kb * BK + w * KPW;
-  const bool active = kw0 < N;   // wave-uniform: a wave whose keys all lie past N only moves data and joins the barriers
-                                 // (tiled build: N is a multiple of 256, every wave of every block is active)
+  int kw0 = kb * BK + w * KPW;
+  const bool active = CT || kw0 < N;   // wave-uniform: a wave whose keys all lie past N only moves data and joins the barriers
+                                       // (tiled builds: N is a multiple of 256, every wave of every block is active)
   frag kf[KC], vf[KC];
   auto load_kv = [&](int k0) {
+    int rr = r, hh = h;
+    if constexpr (CDIAG && TILED) {   // (lane constants re-derived where the unit loop needs them instead of carried through its sweep)
+      const int l2 = lane_fresh();
+      rr = l2 & 31;
+      hh = l2 >> 5;
+    }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const int off = ((k0 + r) * ld + 16 * kc + 8 * h) * (int)sizeof(T);   // rows >= N read as zero
+      const int off = ((k0 + rr) * ld + 16 * kc + 8 * hh) * (int)sizeof(T);   // rows >= N read as zero
       kf[kc] = load_frag_buf<T>(krs, off);
       vf[kc] = load_frag_buf<T>(vrs, off);
     }
@@ -679,7 +695,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) kf[kc] = A::scale(kf[kc], c);
   };
-  const int key = kw0 + r;
+  int key = kw0 + r;
   f32x16 acc_dk[2], acc_dv[2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
@@ -715,10 +731,20 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     k_t0 = stamp();
     k_r0 = __builtin_amdgcn_s_memrealtime();
   }
+  // MODE: which scaling's copy of the sweep the loop holds: 0 = folded, 1 = fp32, 2 = both behind a branch (every build but the causal
+  // tiled one, whose unit loop carries its state around the sweep: with both copies inside it hipcc spilled 187 registers, so that
+  // build takes the branch outside and holds two copies of the whole loop)
+  auto units = [&](auto mode_c) {
+  constexpr int MODE = decltype(mode_c)::value;
+  for (int u = 0;; ++u) {   // units of the causal tiled build (every other build: one pass)
+  int nbh = bh, nkbk = kb, nst0 = 0, nroff = 0;   // (causal tiled build: the unit after this one)
+  bool nsweep = false;
   const int st0 = CDIAG ? 2 * (kb + 1) : 0;   // first stage of the sweep (causal build: the stage below the diagonal block)
   if (!CDIAG || st0 < nst) {
-  stage_dma(st0, slot_of(st0));
-  dma_wait_all();
+  if (!(CT && u > 0)) {   // (later units: requested during the previous unit's diagonal block, published by the barrier behind it)
+    stage_dma(st0, slot_of(st0));
+    dma_wait_all();
+  }
   if constexpr (DIAG) { ph[4] = k_t0 - k_t00; ph[5] = stamp() - k_t0; }   // set-up + fragment-load issue; wait for fragments + stage 0
   // The K / V fragments are tracked loads whose first use sits behind `if (active)`: without an unconditional use HERE (where
   // everything has landed anyway) hipcc re-emits their s_waitcnt vmcnt(7..0) inside the stage loop, where they wait out the
@@ -726,7 +752,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(kf[kc]), "v"(vf[kc]));
   scale_k();
-  __syncthreads();
+  if (!(CT && u > 0)) __syncthreads();
   if constexpr (DIAG) { t0 = stamp(); ph[0] += t0 - k_t0; }
 
   // (two copies of the sweep, one per scaling: the fp32 multiply of the exact one exists in its own instruction stream only)
@@ -847,7 +873,8 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   };
   auto T1 = ic<1>{};
   auto T0 = ic<0>{};
-  for (int t = 0; t < tiles; ++t) {
+  const int heads_here = CDIAG ? 1 : tiles;   // (the causal tiled build loops over its units outside the sweep)
+  for (int t = 0; t < heads_here; ++t) {
   if (TILED && t) {   // the fragments of this head were requested before the previous head's stores (see below)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(kf[kc]), "v"(vf[kc]));
@@ -870,7 +897,7 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     const int nr0 = ra.b[0] + nb, nr1 = ra.b[1] + nb, nh16 = 16 * h + nb;
     if (st + 1 < nst) stage_dma(st + 1, nb);
     else if (CDIAG) stage_dma(2 * kb, nb);   // the first stage of the diagonal block follows the sweep in the ring
-    else if (TILED && t + 1 < tiles) {   // the next head's sweep: its stage 0 follows in the ring
+    else if (TILED && t + 1 < heads_here) {   // the next head's sweep: its stage 0 follows in the ring
       const size_t nbase = head_base(lay, bh + 1);
       qraw = make_raw_rsrc(q + nbase, mat_bytes);
       doraw = make_raw_rsrc(dout + nbase, mat_bytes);
@@ -896,11 +923,11 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     cr0 = nr0; cr1 = nr1; ch16 = nh16;
     ct0 = ta.b[0] + nb; ct1 = ta.b[1] + nb;
   }
-  if constexpr (TILED) {   // hand over to the next head: its fragments are requested before this head's stores are issued
+  if constexpr (TILED && !CDIAG) {   // hand over to the next head: its fragments are requested before this head's stores are issued
     // (requesting them a stage ahead into spare registers, so that the pipeline never refills, spilled: 256 VGPRs + 128 B)
     float* dkrow = dk + base + (size_t)key * ld;
     float* dvrow = dv + base + (size_t)key * ld;
-    if (t + 1 < tiles) {
+    if (t + 1 < heads_here) {
       ++bh;
       base = head_base(lay, bh);
       krs = make_rsrc(k + base, mat_bytes);
@@ -925,9 +952,13 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
   }
   }   // heads of this workgroup
   };
-  if (exact) sweep(ic<1>{});
-  else sweep(ic<0>{});
-  if constexpr (TILED) return;
+  if constexpr (MODE == 2) {
+    if (exact) sweep(ic<1>{});
+    else sweep(ic<0>{});
+  } else {
+    sweep(ic<MODE>{});
+  }
+  if constexpr (TILED && !CDIAG) return;
   }
   if constexpr (CDIAG) {
     // The diagonal block: queries kb * 256 .. + 255 = stages 2 * kb, 2 * kb + 1, in the ring slots of stages nst, nst + 1.
@@ -938,6 +969,26 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
     }
     dma_wait_all();
     __syncthreads();
+    // Causal tiled build: the next unit (the pair's light block, then the next head's heavy one).  The slot of the sweep's last stage
+    // is free from here on (every wave is past the sweep): the next unit's first stage goes there while this block is worked off.
+    if constexpr (CT) {
+      if (u + 1 < nunits) {
+        if (u & 1) { nbh = bh + 1; nkbk = pair; }
+        else nkbk = nkb - 1 - pair;
+        nst0 = 2 * (nkbk + 1);
+        nsweep = nst0 < nst;
+        const size_t nbase = head_base(lay, nbh);
+        qraw = make_raw_rsrc(q + nbase, mat_bytes);      // (the diagonal block below reads LDS only)
+        doraw = make_raw_rsrc(dout + nbase, mat_bytes);
+        nlraw = make_raw_rsrc(nlv + (size_t)nbh * N, (uint32_t)N * 4u);
+        ndraw = make_raw_rsrc(ndelta + (size_t)nbh * N, (uint32_t)N * 4u);
+        if (nsweep) {
+          const int free_slot = (nst + 2 + roff) % 3;                // = the slot of stage nst - 1
+          nroff = ((free_slot - nst0) % 3 + 3) % 3;                  // slot_of(nst0) under the next unit's ring position
+          stage_dma(nst0, free_slot * BUF);
+        }
+      }
+    }
     for (int j = w; j < 8; ++j) {
       lds_char* tq = smem + slot_of(nst + (j >> 2));
       lds_char* tdo = tq + TB;
@@ -1033,7 +1084,51 @@ bwd_dkdv_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* 
       }
     }
   }
+  if constexpr (CT) {
+    if (u + 1 < nunits) {
+      dma_wait_all();     // this wave's pieces of the next unit's first stage have landed
+      __syncthreads();    // every wave is done with the diagonal block's stages; the prefetched stage is published
+      const int l2 = lane_fresh();
+      const int h2 = l2 >> 5;
+      float* dkrow = dk + base + (size_t)(kw0 + (l2 & 31)) * ld;
+      float* dvrow = dv + base + (size_t)(kw0 + (l2 & 31)) * ld;
+      bh = nbh;
+      kb = nkbk;
+      base = head_base(lay, bh);
+      krs = make_rsrc(k + base, mat_bytes);
+      vrs = make_rsrc(v + base, mat_bytes);
+      kw0 = kb * BK + w * KPW;
+      load_kv(kw0);       // requested before the finished unit's stores are issued
+      if (nsweep) roff = nroff;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 a = {acc_dk[dt][4 * g] * tau, acc_dk[dt][4 * g + 1] * tau, acc_dk[dt][4 * g + 2] * tau, acc_dk[dt][4 * g + 3] * tau};
+          f32x4 b = {acc_dv[dt][4 * g], acc_dv[dt][4 * g + 1], acc_dv[dt][4 * g + 2], acc_dv[dt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h2) = a;
+          *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h2) = b;
+        }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        acc_dk[dt] = zero16();
+        acc_dv[dt] = zero16();
+      }
+      continue;
+    }
+  }
+  break;
+  }   // units
+  };
+  if constexpr (CT) {
+    if (exact) units(ic<1>{});
+    else units(ic<0>{});
+  } else {
+    units(ic<2>{});
+  }
+  if constexpr (TILED && !CDIAG) return;
   if constexpr (DIAG) ph[1] += stamp() - t0;
+  if constexpr (CT) key = kw0 + (lane_fresh() & 31);
   if (key < N) {
     float* dkrow = dk + base + (size_t)key * ld;
     float* dvrow = dv + base + (size_t)key * ld;
