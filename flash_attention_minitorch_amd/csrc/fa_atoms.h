@@ -326,6 +326,7 @@ struct Layout {
   // 1 = the operand stays unscaled and every score is multiplied in fp32 (P = exp2(c * S'), the reference's arithmetic), 2 = by the
   // scale guard (fa_common.h: scale_exact).  The forward keeps the pair-of-launches form (its fp32-scaling twin is another kernel).
   int scale_sel;
+  int twin_blocks;       // phased forward launched as the fp32-scaling twin of a guarded call: consecutive query blocks per workgroup
 };
 
 // Counter-based dropout bit of attention position (batch*head bh, query q, key k): a 32-bit finaliser (two

@@ -107,7 +107,7 @@ FA_DEV bool guard_produce(const Layout& L, float qs, float ks, lds_char* scratch
     qm = fmaxf(qm, *FA_LDS(float, scratch + 4 * i));
     km = fmaxf(km, *FA_LDS(float, scratch + 32 + 4 * i));
   }
-  __syncthreads();   // (the scratch is the head of the first K stage: its LDS-DMA follows)
+  __syncthreads();   // (the scratch is part of the stage ring: a later stage's LDS-DMA lands there)
   return !(L.guard_coef * __builtin_sqrtf(qm * km) <= 1.0f);
 }
 template <typename F> FA_DEV float frag_sumsq(const F& f) {

@@ -42,13 +42,16 @@ fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict
   // same number of key tiles and the grid has no long tail (the launcher sizes the grid with fwd_blocks()).
   // ... or, with lay.rank_chunk set, one block per workgroup dispatched longest first across a chunk of heads (map_block_ranked)
   const bool ranked = only_qb < 0 && causal && lay.rank_chunk > 0;
-  const int nblk = only_qb >= 0 ? 1 : ((causal && !ranked) ? (nqb + 1) / 2 : nqb);
+  // (lay.twin_blocks > 1: the launch is the fp32-scaling twin of a guarded non-causal call -- it almost always returns at the guard
+  // check above, and a quarter of the workgroups return in a quarter of the time; each takes that many consecutive query blocks)
+  const int tb = (!causal && only_qb < 0 && lay.twin_blocks > 1) ? lay.twin_blocks : 1;
+  const int nblk = only_qb >= 0 ? 1 : ((causal && !ranked) ? (nqb + 1) / 2 : nqb / tb);
   int bh, pblk;
   if (ranked) map_block_ranked(blockIdx.x, BH, nblk, lay.rank_chunk, bh, pblk);
   else map_block(blockIdx.x, BH, nblk, bh, pblk);
-  const int npass = (only_qb < 0 && causal && !ranked && pblk != nqb - 1 - pblk) ? 2 : 1;
+  const int npass = tb > 1 ? tb : ((only_qb < 0 && causal && !ranked && pblk != nqb - 1 - pblk) ? 2 : 1);
   for (int pass = 0; pass < npass; ++pass) {
-  const int qb = only_qb >= 0 ? only_qb : (causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk);
+  const int qb = only_qb >= 0 ? only_qb : (causal ? (pass == 0 ? nqb - 1 - pblk : pblk) : pblk * tb + pass);
   const int q0 = qb * 128 + w * 32, qrow = q0 + r;
   const bool qvalid = qrow < N;
   // wave-uniform: this wave's rows may see fewer than 64 admissible keys (or a mask / dropout thins them): operands that the
@@ -445,26 +448,15 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   // which stay.  Not the causal build: it sits at its 128 registers and spilled two to three around this in either order (causal
   // calls take the separate guard pass).
   const bool produce = PRE && !CDIAG && lay.guard_want == 2 && lay.guard != nullptr;
-  float ks = 0.f;
+  frag kg[KC];   // (the key rows of the query rows' indices: requested here, summed behind the first stages' LDS-DMA, see below)
   if (produce) {
     const rsrc_t krs = make_rsrc(k + base, mat_bytes);
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) ks += frag_sumsq(load_frag_buf<T>(krs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T)));
-    asm volatile("" : "+v"(ks));
+    for (int kc = 0; kc < KC; ++kc) kg[kc] = load_frag_buf<T>(krs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
   }
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) qf[kc] = load_frag_buf<T>(qrs, (qrow * ld + 16 * kc + 8 * h) * (int)sizeof(T));
-  if (produce) {
-    float qs = 0.f;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) qs += frag_sumsq(qf[kc]);
-    if (guard_produce(lay, qs, ks, smem)) return;   // (workgroup-uniform)
-  }
   const bool exactq = CDIAG && A::SPLITS && q0 < 64;   // wave-uniform: rows with fewer than 64 admissible keys (query block 0 only)
-  if (PRE && !exactq) {
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) qf[kc] = A::scale(qf[kc], c);
-  }
   const float cm = (PRE && !exactq) ? 1.0f : c;   // what a score of this wave's MFMA chain is multiplied by to reach log2 units
   f32x16 acc_o[DT];
 #pragma unroll
@@ -513,6 +505,22 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
   {
   stage_dma(0, 0);
   if (NSUBT == 2 && (CDIAG || nstage > 1)) stage_dma(ST, slot_of(1));
+  if (produce) {   // the guard's row norms, while the first stages are in flight (scratch: the tail of the ring, written by stage R - 1 first)
+    float qs = 0.f, ks = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      qs += frag_sumsq(qf[kc]);
+      ks += frag_sumsq(kg[kc]);
+    }
+    if (guard_produce(lay, qs, ks, smem + 2 * R * TB - 64)) {   // (workgroup-uniform)
+      dma_wait_all();   // (no LDS-DMA may land after the workgroup has given its LDS back)
+      return;
+    }
+  }
+  if (PRE && !exactq) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qf[kc] = A::scale(qf[kc], c);
+  }
   dma_wait_all();
   __syncthreads();
   if constexpr (DIAG == 1) { t0 = stamp(); ph[0] += t0 - k_t0; }
