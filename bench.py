@@ -463,6 +463,7 @@ def main():
 
     # ---- per-kernel average launch duration from the HIP events recorded in the timed region -------------------
     kernels = {}
+    kernel_rooflines = None
     roofline = None
     if breakdown:
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
@@ -475,6 +476,15 @@ def main():
             kernels[name] = (ms, alg[name])
         dom = STAGES[dom_stage][0]
         dur_ms, fl = kernels[dom]
+        # every kernel against the same roofline, counted (algorithmic) and executed work: the dQ kernel recomputes S^T and dP^T
+        # (6 GEMM units executed for the 2 it is credited with); stage times include the launches that return at the guard check
+        executed = {K_FWD: flops_fw, K_DKDV: 8.0 * BH * N * N * d * cf, K_DQ: 6.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw}
+        pk = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        kernel_rooflines = {n: {"ms": round(ms_, 4), "algorithmic_tflops": round(fl_ / (ms_ * 1e-3) / 1e12, 1),
+                                "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / pk, 4),
+                                "executed_tflops": round(executed.get(n, fl_) / (ms_ * 1e-3) / 1e12, 1),
+                                "executed_frac": round(executed.get(n, fl_) / (ms_ * 1e-3) / 1e12 / pk, 4)}
+                            for n, (ms_, fl_) in kernels.items() if fl_ > 0 and ms_ > 0}
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = fl / (dur_ms * 1e-3) / 1e12
         traffic = None
@@ -582,6 +592,7 @@ def main():
             "sustained_mfma_peak": sustained,
             "cpu_baseline": cpu_baseline,
             "kernels_ms": {n: round(t, 4) for n, (t, _) in kernels.items()},
+            "kernel_rooflines": kernel_rooflines,
             "kernels_ms_source": "HIP events: roofline.kernel inside the timed region (two events per step); the others over the "
                                  "same number of untimed steps just before the warm-up (an event per kernel boundary)",
             "kernels_ms_sum_note": "the entries come from two passes (see kernels_ms_source) and the untimed pass carries an event at "
