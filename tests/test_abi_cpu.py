@@ -149,6 +149,22 @@ def test_argument_validation_without_gpu(built):
     chain = (ctypes.c_int * 5)(0, 0, 0, 0, 3)
     assert core.fa_mi355x_bwd_workspace_bytes_ex(64, 4096, 64, chain, 5) == 3 * 64 * 4096 * 4
     assert core.fa_mi355x_bwd_workspace_bytes_ex(64, 4096, 64, None, 0) == 3 * 64 * 4096 * 4
+    # round 4: the scale guard and the guarded entry points validate their arguments before any HIP call as well
+    core.fa_mi355x_guard_bytes.restype = ctypes.c_size_t
+    assert core.fa_mi355x_guard_bytes() == 2 * 256 * 4
+    core.fa_mi355x_scale_guard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert core.fa_mi355x_scale_guard(null, one, 16, 64, 1, one, null) == 1 and core.fa_mi355x_scale_guard(one, one, 0, 64, 1, one, null) == 1
+    assert core.fa_mi355x_scale_guard(one, one, 16, 64, 7, one, null) == 1
+    fw = core.fa_mi355x_fwd_guarded
+    fw.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5 + [ctypes.c_float] + [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    assert fw(one, one, one, one, one, one, 1, 1, 16, 64, 0, 0.0, 0, 2, 1, None, 0, null, 1, null) == 1      # produce_guard without a guard
+    assert b"produce_guard" in core.fa_mi355x_last_error()
+    assert fw(one, one, one, one, one, one, 1, 1, 16, 64, 0, -1.0, 0, 2, 1, None, 0, null, 0, null) == 1     # negative softmax_scale
+    assert fw(one, one, one, one, one, one, 1, 1, 16, 64, 5, 0.0, 0, 2, 1, None, 0, null, 0, null) == 1      # unknown layout
+    assert fw(one, one, one, one, one, one, 1, 1, 16, 48, 0, 0.0, 0, 2, 1, None, 0, null, 0, null) == 2      # head dim
+    mode9 = (ctypes.c_int * 10)(0, 0, 0, 0, 0, 0, 0, 0, 4, 0)
+    assert fw(one, one, one, one, one, one, 1, 1, 16, 64, 0, 0.0, 0, 2, 1, mode9, 10, null, 0, null) == 1    # option 8 = 4 does not exist
     # per-call options: diagnostic values are rejected by the product library before any HIP call
     bad = (ctypes.c_int * 3)(93, 0, 0)
     assert core.fa_mi355x_fwd_ex(one, one, one, one, one, one, 1, 16, 64, 0, 2, 0, bad, 3, null) == 1
