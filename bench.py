@@ -92,7 +92,8 @@ def guarded_call(BH, N, d, causal, dtype, opts):
 
 def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd, guarded=False):
     """The step as a list of (kernel name, callable) in the library's own launch order, from fa_mi355x_plan.  A backward plan without
-    bwd_prep_kernel means the dQ launch preprocesses its own rows and runs first; bwd_fused_kernel is the opt-in one-pass backward.
+    bwd_prep_kernel means the dQ launch preprocesses its own rows and runs first; bwd_onepass_f32_kernel is the fp32 d = 64 one-pass
+    backward (bwd_fused_kernel the diagnostic library's bf16 one).
     guarded (a step under the scale guard): every stage is the launch of the named kernel plus the launch of its fp32-scaling twin,
     which returns at once for operands inside the guard's budget (the names are those of the chosen side); the forward stage also
     zero-fills the 2-KiB guard that its launch then fills."""
@@ -104,9 +105,10 @@ def stage_plan(device_ops, BH, N, d, causal, dtype, opts, fwd, bwd, guarded=Fals
     k_fwd = main(plan(0))
     whole = plan(device_ops.STAGE_ALL)
     k_dq, k_dkdv = main(plan(device_ops.STAGE_DQ)), main(plan(device_ops.STAGE_DKDV))
-    if "bwd_fused_kernel" in whole:
+    onepass = [n for n in whole if n in ("bwd_fused_kernel", "bwd_onepass_f32_kernel")]
+    if onepass:   # (fp32, d = 64: the one-pass backward is the default; k_dq / k_dkdv name the two-kernel path of a split call)
         stages = ((k_fwd, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
-                  ("bwd_fused_kernel", lambda: bwd(device_ops.STAGE_DKDV | device_ops.STAGE_DQ)))
+                  (onepass[0], lambda: bwd(device_ops.STAGE_DKDV | device_ops.STAGE_DQ)))
     elif "bwd_prep_kernel" in whole:
         stages = ((k_fwd, fwd), ("bwd_prep_kernel", lambda: bwd(device_ops.STAGE_PREP)),
                   (k_dkdv, lambda: bwd(device_ops.STAGE_DKDV)), (k_dq, lambda: bwd(device_ops.STAGE_DQ)))

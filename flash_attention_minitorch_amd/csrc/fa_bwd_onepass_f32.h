@@ -1,0 +1,194 @@
+// FlashAttention backward for MI355X (gfx950), fp32 (the reference's own dtype), d = 64, non-causal, N a multiple of 256: ONE pass for
+// dQ, dK and dV -- the five products of the reference's single-pass FA-2 backward (src/flash_attn2_bw.cu:94-247: S, dP, dV, dK, dQ),
+// dQ summed over the key blocks with fp32 atomics as the reference does (:228).  Part of the kernel set described in fa_kernels.h.
+//
+// Why it pays HERE and not for bf16 (fa_bwd_chain.h, profiles/r04_chain_backward.txt): the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 /
+// 16x16x4_f32) runs at 1/16 of the bf16 rate, so the kernel is MFMA-bound by a wide margin and the two-kernel backward's seven
+// products for five cost their full 40 %; the same dQ adds (N/256 per element) that exceed the chip's ~1.3 TB/s atomic rate beside
+// bf16 MFMAs need a third of it beside fp32 ones (0.45 TB/s at any N: bytes and time both grow with N^2), spread evenly over the
+// kernel (every 32-query stage adds its tile), and hide.
+//
+// Geometry: a workgroup = 8 waves x 32 keys = one 256-key block of one (batch*head); K, V fragments and the dK^T, dV^T accumulators
+// of a wave's keys in registers (as bwd_dkdv_kernel).  It sweeps 32-query stages (Q, dO tiles and the rows' -L/tau, -delta, register
+// staged into a double buffer).  Per stage every wave forms S' = Q K^T - L/tau and dP' = dO V^T - delta (row constants as MFMA
+// accumulator inputs), P = exp2(c S'), dS = P o dP', dV^T += dO^T P, dK^T += Q^T dS from registers, and writes its 32 x 32 block of dS
+// to an LDS image [query][key]; after a barrier wave w forms ONE 16 x 16 tile of dQ = dS K over all 256 keys (query block w >> 2, column
+// block w & 3) with 64 v_mfma_f32_16x16x4_f32 -- dS rows and K columns (an LDS image of the block's 256 key rows) as one scalar LDS
+// read per lane and MFMA -- and adds tau * tile to dq: four no-return atomics per wave and stage, each register four whole 64-byte row
+// segments.  dq must be zero on entry (the launcher fills it; the reference's caller does the same, minitorch/cuda_kernel_ops.py:609-611).
+#pragma once
+#include "fa_common.h"
+
+namespace fa {
+
+constexpr int OP32_QS = 32, OP32_BK = 256;
+constexpr int OP32_TB = (OP32_QS * (64 + 4)) * 4;                 // one 32 x 64 fp32 tile, rows padded by 16 B
+constexpr int OP32_STG = 2 * OP32_TB + 8 * OP32_QS;               // Q tile, dO tile, 32 x (-L/tau), 32 x (-delta)
+constexpr int OP32_KIMG = (OP32_BK * (64 + 4)) * 4;               // the block's 256 key rows
+constexpr int OP32_DSROW = OP32_BK + 4;                           // floats per row of the dS image (pad: a lane pair's rows 4 apart)
+constexpr int OP32_DS = OP32_QS * OP32_DSROW * 4;
+constexpr int OP32_SMEM = 2 * OP32_STG + OP32_KIMG + OP32_DS;     // 138,240 B: one workgroup per CU, two waves per SIMD
+
+template <int D>
+__global__ void __launch_bounds__(512, 2)
+bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                       const float* __restrict__ dout, const float* __restrict__ nlc, const float* __restrict__ ndelta,
+                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int N, int nkb, int BH, Layout lay,
+                       float tau) {
+  if (guard_skip(lay)) return;
+  static_assert(D == 64, "laid out for d = 64");
+  using A = Atom<float>;
+  typedef typename A::frag frag;
+  constexpr int KC = D / 16, DT = D / 32, QS = OP32_QS, TB = OP32_TB, STG = OP32_STG, KIMG = 2 * OP32_STG, DSB = KIMG + OP32_KIMG;
+  __shared__ __attribute__((aligned(16))) char smem_raw[OP32_SMEM];
+  lds_char* smem = (lds_char*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, kb;
+  map_block(blockIdx.x, BH, nkb, bh, kb);
+  const size_t base = head_base(lay, bh);
+  const int ld = lay.ld;
+  const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * 4u;
+  const rsrc_t qrs = make_rsrc(q + base, mat_bytes), dors = make_rsrc(dout + base, mat_bytes);
+  const rsrc_t krs = make_rsrc(k + base, mat_bytes), vrs = make_rsrc(v + base, mat_bytes);
+  const rsrc_t dqrs = make_rsrc(dq + base, mat_bytes);
+  const float* nlg = nlc + (size_t)bh * N;
+  const float* deg = ndelta + (size_t)bh * N;
+  const float c = tau * LOG2E;
+  const int kb0 = kb * OP32_BK, kw0 = kb0 + 32 * w;
+
+  frag vf[KC];   // (the wave's K fragments are re-read from the key image every stage: 32 registers for 8 LDS reads)
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) vf[kc] = load_frag_buf<float>(vrs, ((kw0 + r) * ld + 16 * kc + 8 * h) * 4);
+  {   // the block's key rows as an LDS image (the B operand of dQ = dS K by column reads)
+    TileStager<float, D, OP32_BK, 512> sk;
+    sk.init(tid, ld);
+    sk.load(krs, kb0);
+    sk.store(smem + KIMG);
+  }
+  f32x16 acc_dk[DT], acc_dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    acc_dk[dt] = zero16();
+    acc_dv[dt] = zero16();
+  }
+  const LaneAddr ra = A::template row_addr<D>(lane);
+  const LaneAddr ta = A::template tr_addr<D>(lane);
+  TileStager<float, D, QS, 512> sq, sdo;
+  sq.init(tid, ld);
+  sdo.init(tid, ld);
+  float st_nl = 0.f, st_de = 0.f;
+  auto stage_load = [&](int qi) {
+    sq.load(qrs, qi * QS);
+    sdo.load(dors, qi * QS);
+    if (tid < QS) {
+      st_nl = nlg[qi * QS + tid];
+      st_de = deg[qi * QS + tid];
+    }
+  };
+  auto stage_store = [&](lds_char* b) {
+    sq.store(b);
+    sdo.store(b + TB);
+    if (tid < QS) {
+      *FA_LDS(float, b + 2 * TB + 4 * tid) = st_nl;
+      *FA_LDS(float, b + 2 * TB + 4 * QS + 4 * tid) = st_de;
+    }
+  };
+  // dQ tile of this wave: query block qb (16 rows), column block db (16 columns).  v_mfma_f32_16x16x4_f32: lane (i16, g4) supplies
+  // A[i16][g4] = dS[16 qb + i16][key k0 + g4] and B[g4][i16] = K[key k0 + g4][16 db + i16]; its four result registers are rows
+  // 4 g4 + j of column i16.
+  const int i16 = lane & 15, g4 = lane >> 4, qb = w >> 2, db = w & 3;
+  const int ds_rd = DSB + ((16 * qb + i16) * OP32_DSROW + g4) * 4;
+  const int k_rd = KIMG + (g4 * (D + 4) + 16 * db + i16) * 4;
+  const int ds_wr = DSB + (32 * w + r) * 4;   // this lane's key column of the dS image; row acc_row(i, h)
+  const int dq_voff = ((16 * qb + 4 * g4) * ld + 16 * db + i16) * 4;
+
+  const int nqi = N / QS;
+  stage_load(0);
+  stage_store(smem);
+  __syncthreads();
+
+  auto slice = [&](auto par, int qi) {
+    constexpr int PAR = decltype(par)::value;
+    const bool more = qi + 1 < nqi;
+    if (more) stage_load(qi + 1);
+    lds_char* tq = smem + PAR * STG;
+    lds_char* tdo = tq + TB;
+    f32x16 nl16, nd16, s, dp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 a = *FA_LDS(f32x4, tq + 2 * TB + 16 * h + 32 * g);
+      const f32x4 b = *FA_LDS(f32x4, tq + 2 * TB + 4 * QS + 16 * h + 32 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        nl16[4 * g + i] = a[i];
+        nd16[4 * g + i] = b[i];
+      }
+    }
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const frag aq = A::template row_frag<D>(tq, ra, 0, kc);
+      const frag ado = A::template row_frag<D>(tdo, ra, 0, kc);
+      const frag kfr = A::template row_frag<D>(smem + KIMG, ra, 32 * w, kc);
+      if (kc == 0) {   // row constants ride in as accumulator inputs: S' = S - L/tau, dP' = dP - delta
+        A::mma_c(s, aq, kfr, nl16);
+        A::mma_c(dp, ado, vf[kc], nd16);
+      } else {
+        A::mma(s, aq, kfr);
+        A::mma(dp, ado, vf[kc]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __builtin_amdgcn_exp2f(s[i] * c);
+      dp[i] = s[i] * dp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *FA_LDS(float, smem + ds_wr + acc_row(i, h) * OP32_DSROW * 4) = dp[i];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        A::mma(acc_dv[dt], A::template tr_frag<D>(tdo, ta, 16 * s2, dt), A::pack(s, s2));
+        A::mma(acc_dk[dt], A::template tr_frag<D>(tq, ta, 16 * s2, dt), A::pack(dp, s2));
+      }
+    __syncthreads();   // the stage's dS image is complete
+    f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {   // (two halves: the K image's 128-row offset does not fit the instruction's 16-bit immediate)
+      const int kr = k_rd + half * 128 * (D + 4) * 4, dr = ds_rd + half * 128 * 4;
+#pragma unroll
+      for (int st = 0; st < 32; ++st) {
+        const float a = *FA_LDS(float, smem + dr + 16 * st);
+        const float b = *FA_LDS(float, smem + kr + st * 4 * (D + 4) * 4);
+        t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t4, 0, 0, 0);
+      }
+    }
+    const int soff = qi * QS * ld * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(t4[j] * tau, dqrs, dq_voff, soff + j * ld * 4, 0);
+    if (more) stage_store(smem + (PAR ^ 1) * STG);
+    __syncthreads();   // the next stage is published; every wave is done with this stage's dS image
+  };
+  int qi = 0;
+  for (; qi + 1 < nqi; qi += 2) {
+    slice(ic<0>{}, qi);
+    slice(ic<1>{}, qi + 1);
+  }
+  if (qi < nqi) slice(ic<0>{}, qi);
+
+  float* dkrow = dk + base + (size_t)(kw0 + r) * ld;
+  float* dvrow = dv + base + (size_t)(kw0 + r) * ld;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a = {acc_dk[dt][4 * g] * tau, acc_dk[dt][4 * g + 1] * tau, acc_dk[dt][4 * g + 2] * tau, acc_dk[dt][4 * g + 3] * tau};
+      f32x4 b = {acc_dv[dt][4 * g], acc_dv[dt][4 * g + 1], acc_dv[dt][4 * g + 2], acc_dv[dt][4 * g + 3]};
+      *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h) = a;
+      *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h) = b;
+    }
+}
+
+}  // namespace fa

@@ -34,6 +34,7 @@
 #include "fa_fwd.h"
 #include "fa_bwd_dkdv.h"
 #include "fa_bwd_dq.h"
+#include "fa_bwd_onepass_f32.h"
 #ifdef FA_DIAG
 #include "fa_bwd_fused.h"   // the one-pass backward: diagnostic build only (tools/check_fused.py)
 #include "fa_bwd_chain.h"   // its round-4 form (chained key blocks, fp32 atomics from the last one): tools/check_chain.py

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""GPU check of the fp32 one-pass backward (bwd_onepass_f32_kernel: the default for fp32, d = 64, non-causal, N % 256 == 0) against
+the fp64 oracle and the two-kernel backward (option 4 = 4), plus timing of both.
+usage: python tools/check_onepass_f32.py [--time]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from flash_attention_minitorch_amd import _lib, device_ops  # noqa: E402
+
+TWO = (0, 0, 0, 0, 4)
+
+
+def run(B, H, N, d=64, seed=0, heads=None, scale=1.0, variant=None):
+    rng = np.random.default_rng(seed)
+    qf, kf, vf, dof = ((scale * rng.uniform(-1, 1, (B * H, N, d))).astype(np.float32) for _ in range(4))
+    tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda") for a in (qf, kf, vf, dof))
+    variant = _lib.FA_VARIANT_FA2 if variant is None else variant
+    o, L, M = device_ops.flash_attn_fwd(tq, tk, tv, False, variant)
+    g2 = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, False, variant, opts=TWO)]
+    g1 = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, False, variant)]
+    g1b = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, False, variant)]
+    torch.cuda.synchronize()
+    names = ("dq", "dk", "dv")
+    msg = [f"B{B} H{H} N{N} v{variant}"]
+    ok = True
+    for n_, a, b, c in zip(names, g1, g2, g1b):
+        dsplit = float((a - b).abs().max())
+        drep = float((a - c).abs().max())
+        msg.append(f"{n_}: |one-two|={dsplit:.2e} |rerun|={drep:.1e}")
+        ok &= dsplit < 2e-5 * scale * scale and bool(torch.isfinite(a).all()) and drep < 1e-5 * scale * scale
+    hs = range(B * H) if heads is None else heads
+    worst = 0.0
+    for hh in hs:
+        refs = oracle.dense_attention_bw(qf[hh:hh + 1], kf[hh:hh + 1], vf[hh:hh + 1], dof[hh:hh + 1])
+        for n_, a, ref in zip(names, g1, refs):
+            e = float(np.max(np.abs(a[hh].cpu().numpy() - ref[0])))
+            worst = max(worst, e)
+            if e > 1e-4 * scale * scale:
+                ok = False
+                msg.append(f"  head {hh} {n_} err {e:.2e} !!")
+    msg.append(f"oracle max err {worst:.2e}")
+    print(("OK   " if ok else "FAIL ") + " | ".join(msg), flush=True)
+    return ok
+
+
+def timeit(B, H, N, d=64, iters=20):
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda: (torch.rand((B * H, N, d), device="cuda", generator=gen) - 0.5) * 2
+    q, k, v, do = mk(), mk(), mk(), mk()
+    o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal=False)
+    ws = device_ops.bwd_workspace(q)
+    grads = tuple(torch.empty((B * H, N, d), dtype=torch.float32, device="cuda") for _ in range(3))
+    res = {}
+    for name, opts in (("two", TWO), ("one", None), ("two2", TWO), ("one2", None)):
+        for _ in range(5):
+            device_ops.flash_attn_bwd(q, k, v, o, do, L, workspace=ws, grads=grads, opts=opts)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            device_ops.flash_attn_bwd(q, k, v, o, do, L, workspace=ws, grads=grads, opts=opts)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters
+    fl = 10.0 * B * H * N * N * d
+    print(f"time B{B} H{H} N{N}: " + "  ".join(f"{k}={v:.4f} ms ({fl / v / 1e9:.1f} TF/s)" for k, v in res.items()), flush=True)
+
+
+if __name__ == "__main__":
+    good = True
+    good &= run(1, 1, 256)
+    good &= run(1, 2, 512)
+    good &= run(2, 3, 1024, seed=3)
+    good &= run(1, 20, 768, seed=4, heads=[0, 7, 19])
+    good &= run(8, 8, 1024, seed=5, heads=[0, 13, 63])     # configs[1]
+    good &= run(8, 8, 2048, seed=6, heads=[0, 63])         # configs[2]
+    good &= run(8, 8, 2048, seed=6, heads=[5], variant=_lib.FA_VARIANT_FA1)
+    good &= run(3, 7, 1280, seed=7, heads=[0, 20], scale=3.0)
+    print("ALL OK" if good else "SOME FAILED", flush=True)
+    if "--time" in sys.argv:
+        timeit(8, 8, 1024)
+        timeit(8, 8, 2048)
+        timeit(8, 8, 4096)
+        timeit(32, 8, 1024)
+        timeit(2, 8, 8192)
+    sys.exit(0 if good else 1)
