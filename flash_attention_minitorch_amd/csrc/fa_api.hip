@@ -175,7 +175,7 @@ inline size_t chain_extra_bytes(int batch, int N, int d, int cus) {
   if (!chain_shape(N, d)) return 0;
   const int nchains = chain_count(batch, N, cus), nkb = N / 256;
   size_t b = fa::CHAIN_HDR;
-  if (nchains > 1 && nchains < nkb) b += (size_t)batch * nchains * (size_t)N * 256u;
+  if (nchains < nkb) b += (size_t)batch * nchains * (size_t)N * 256u;   // running sums of chains of more than one key block
   return b;
 }
 #else
@@ -463,14 +463,14 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
 // which reads the workspace the dQ launch wrote)?  Yes whenever dq_stage sends the call to a plain main build: not under a key mask
 // or dropout, not bf16 with N < 64 (split-operand builds), not the bf16 d = 64 slot build with masked periods (no registers), not a
 // diagnostic build; option 4 = 1 keeps the separate preprocess kernel (A/B), 2 is the one-pass backward.
-// fp32, d = 64, non-causal, N a multiple of 256, no key mask / dropout, dQ and dK/dV asked for together: the one-pass backward
+// fp32, d = 64, N a multiple of 256, no key mask / dropout, dQ and dK/dV asked for together: the one-pass backward
 // (fa_bwd_onepass_f32.h: five products instead of the two-kernel path's seven, dQ by fp32 atomics).  Option 4 = 4 keeps two kernels
 // (dq bitwise repeatable from run to run).
 template <typename T, int D>
 bool onepass_f32(int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
   const int both = FA_BWD_STAGE_DKDV | FA_BWD_STAGE_DQ;
-  return sizeof(T) == 4 && D == 64 && (stages & both) == both && tun.v[4] == 0 && !causal && !lay.kmask && !lay.drop_thr &&
-         N >= 256 && N % 256 == 0;
+  return sizeof(T) == 4 && D == 64 && (stages & both) == both && tun.v[4] == 0 && !lay.kmask && !lay.drop_thr && N >= 256 &&
+         N % 256 == 0;
 }
 
 template <typename T, int D>
@@ -577,8 +577,14 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       // [B][N][H][d] or [BH][N][d]: the tensor is one contiguous range either way
       if (!t_probe && !t_plan) FA_HIP_TRY(hipMemsetAsync(dq, 0, (size_t)rows * D * sizeof(float), st));
       const int nkb = N / 256;
-      FA_LAUNCH((fa::bwd_onepass_f32_kernel<D>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q, (const float*)k,
-                (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau);
+      if (causal) {   // key block 0 (the longest sweep) of a chunk of heads first
+        lay.rank_chunk = rank_chunk(1, nkb);
+        FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, true>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q,
+                  (const float*)k, (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau);
+      } else {
+        FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, false>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q,
+                  (const float*)k, (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau);
+      }
       FA_HIP_TRY(hipGetLastError());
       return FA_OK;
     }

@@ -12,10 +12,15 @@
 // dQ tiles of its chain through memory with PLAIN loads and stores (about 6 TB/s, no ordering protocol: the wave that stored a
 // tile is the wave that loads it a key block later); only the last key block of a chain ends in the cross-workgroup sum:
 //
-//   * nchains == 1 (a whole head per workgroup: enough heads to fill the chip): no atomics at all, dq itself holds the running
-//     sums, the last key block scales by tau and overwrites them.  Bitwise reproducible, no workspace, no zero-fill.
-//   * nchains > 1 (B*H < CUs; the metric shape: 4 chains of 4 key blocks): running sums in a private slab per workgroup
-//     (register-major: every store instruction writes 1 KiB contiguous), the last key block adds tau * sum to dq with
+//   * nchains == 1 (a whole head per workgroup: enough heads to fill the chip): no atomics at all, the last key block scales the
+//     sum by tau and stores it to dq.  Bitwise reproducible, no zero-fill.  (Until the end of round 4 dq ITSELF held the running sums
+//     of this form, a lane's 16 bytes at their final place: a 128-byte line of dq is then written by the separate store instructions
+//     of two waves and re-read with sc1 loads while the other half is in flight.  One run in about ten of tools/check_chain.py came
+//     back with one wrong dq tile at B=32 H=8 N=1024 -- outside the hand-off forms MI355X_MICROARCH.md lists as measured valid, which
+//     all write whole lines by one store instruction of one wave -- so this form now keeps its sums in the slab as well.)
+//   * running sums (both forms) in a private slab per workgroup
+//     (register-major: every store instruction writes 1 KiB contiguous);
+//   * nchains > 1 (B*H < CUs; the metric shape: 4 chains of 4 key blocks): the last key block adds tau * sum to dq with
 //     no-return fp32 atomics (dq zero-filled by the launcher): N / (256 * C) adds per element instead of N / 256, which at
 //     C = 4 is a quarter of the atomic floor (0.21 ms at the metric shape) and hides under the chain's MFMA work.  The
 //     dQ tile is formed as dQ[q][d] with d on the lane there (the MFMA's operands swapped), so one accumulator register of a
@@ -272,17 +277,18 @@ bwd_chain_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __re
   auto T0 = ic<0>{};
   auto NO = ic<-1>{};
 
-  // Running tiles of this wave.  ATOMIC (private slab, register-major): pair u at slab_w + u * 16 KiB, tile qb at + qb * 1 KiB, a
-  // lane's 16 bytes at lane * 16.  Otherwise dq itself: a lane's 16 bytes are 4 consecutive d of one query row.
+  // Running tiles of this wave: a private slab, register-major: pair u at slab_w + u * 16 KiB, tile qb at + qb * 1 KiB, a lane's
+  // 16 bytes at lane * 16.  The last key block of the non-atomic form stores to dq: a lane's 16 bytes are 4 consecutive d of a row.
   const uint32_t dq_bytes = ((uint32_t)(N - 1) * ld + D) * 4u;
   const rsrc_t dqrs = make_rsrc(dq + base, dq_bytes);
-  const uint32_t slab_bytes = ATOMIC ? (uint32_t)CHAIN_HDR + (uint32_t)N * 256u : dq_bytes;
-  const rsrc_t srs = ATOMIC ? make_rsrc(reinterpret_cast<char*>(slab) + (size_t)blockIdx.x * (size_t)N * 256u, slab_bytes) : dqrs;
+  const uint32_t slab_bytes = (uint32_t)CHAIN_HDR + (uint32_t)N * 256u;
+  const rsrc_t srs = make_rsrc(reinterpret_cast<char*>(slab) + (size_t)blockIdx.x * (size_t)N * 256u, slab_bytes);
   const rsrc_t dummy_rs = make_rsrc(slab, (uint32_t)CHAIN_HDR);
-  const int t_voff = ATOMIC ? lane * 16 : ((32 * ss + i16) * ld + 16 * db + 4 * g4) * 4;
-  const int t_w = ATOMIC ? CHAIN_HDR + w * 2048 : 0;           // this wave's tiles of pair 0
-  const int t_pair = (ABL & 2048) ? 0 : (ATOMIC ? 16384 : HS * ld * 4);   // bytes from pair to pair
-  const int t_d2 = ATOMIC ? 1024 : 16 * ld * 4;                // ... from query block 0 to 1
+  const int t_voff = lane * 16;
+  const int t_w = CHAIN_HDR + w * 2048;                        // this wave's tiles of pair 0
+  const int t_pair = (ABL & 2048) ? 0 : 16384;                 // bytes from pair to pair
+  const int t_d2 = 1024;                                       // ... from query block 0 to 1
+  const int f_voff = ((32 * ss + i16) * ld + 16 * db + 4 * g4) * 4;   // the non-atomic form's final store
   // the atomic form's element map: register j of tile qb -> row 32 ss + 16 qb + 4 g4 + j, column 16 db + i16
   const int a_voff = ((32 * ss + 4 * g4) * ld + 16 * db + i16) * 4;
 
@@ -350,7 +356,7 @@ bwd_chain_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __re
       ld_on = !first && u >= 0;
       st_on = u2 >= 0;
       ld_soff = t_w + ((ABL & 4096) ? 0 : u * t_pair);   // (4096: loads from one L2-resident spot, stores at full stride)
-      st_soff = (last && ATOMIC) ? HS * u2 * ld * 4 : t_w + ((ABL & 8192) ? 0 : u2 * t_pair);   // (8192: the reverse)
+      st_soff = last ? HS * u2 * ld * 4 : t_w + ((ABL & 8192) ? 0 : u2 * t_pair);   // (8192: the reverse)
     };
     f32x4 s0 = zero4, s1 = zero4;
     auto ho_load = [&](int which) {
@@ -377,6 +383,11 @@ bwd_chain_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __re
             for (int j = 0; j < 4; ++j)
               __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sv[j], dqrs, a_voff, st_soff + (16 * which + j) * ld * 4, 0);
           }
+          return;
+        }
+      } else {
+        if (last) {
+          if (st_on) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv), dqrs, f_voff, st_soff + which * 16 * ld * 4, 0);
           return;
         }
       }

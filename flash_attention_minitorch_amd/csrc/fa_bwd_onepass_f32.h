@@ -1,4 +1,4 @@
-// FlashAttention backward for MI355X (gfx950), fp32 (the reference's own dtype), d = 64, non-causal, N a multiple of 256: ONE pass for
+// FlashAttention backward for MI355X (gfx950), fp32 (the reference's own dtype), d = 64, N a multiple of 256: ONE pass for
 // dQ, dK and dV -- the five products of the reference's single-pass FA-2 backward (src/flash_attn2_bw.cu:94-247: S, dP, dV, dK, dQ),
 // dQ summed over the key blocks with fp32 atomics as the reference does (:228).  Part of the kernel set described in fa_kernels.h.
 //
@@ -15,7 +15,11 @@
 // to an LDS image [query][key]; after a barrier wave w forms ONE 16 x 16 tile of dQ = dS K over all 256 keys (query block w >> 2, column
 // block w & 3) with 64 v_mfma_f32_16x16x4_f32 -- dS rows and K columns (an LDS image of the block's 256 key rows) as one scalar LDS
 // read per lane and MFMA -- and adds tau * tile to dq: four no-return atomics per wave and stage, each register four whole 64-byte row
-// segments.  dq must be zero on entry (the launcher fills it; the reference's caller does the same, minitorch/cuda_kernel_ops.py:609-611).
+// segments.  CAUSAL (the reference's causal kernels skip and mask the same way: src/flash_attn_causal_bw.cu, the j > i tiles): key
+// block kb starts its sweep at its own queries; on the 8 diagonal stages the waves whose keys are all masked sit out, the wave on the
+// diagonal masks above it, and dQ sums the live keys only; blocks are dispatched longest sweep first (map_block_ranked).  Measured
+// (profiles/r04_onepass_f32.txt): 131 vs 98 TFLOP/s non-causal and 117 vs 86 causal at B=8 H=8 N=2048 against the two-kernel path.
+// dq must be zero on entry (the launcher fills it; the reference's caller does the same, minitorch/cuda_kernel_ops.py:609-611).
 #pragma once
 #include "fa_common.h"
 
@@ -29,7 +33,7 @@ constexpr int OP32_DSROW = OP32_BK + 4;                           // floats per 
 constexpr int OP32_DS = OP32_QS * OP32_DSROW * 4;
 constexpr int OP32_SMEM = 2 * OP32_STG + OP32_KIMG + OP32_DS;     // 138,240 B: one workgroup per CU, two waves per SIMD
 
-template <int D>
+template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(512, 2)
 bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                        const float* __restrict__ dout, const float* __restrict__ nlc, const float* __restrict__ ndelta,
@@ -46,7 +50,8 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bh, kb;
-  map_block(blockIdx.x, BH, nkb, bh, kb);
+  if (CAUSAL) map_block_ranked(blockIdx.x, BH, nkb, max(lay.rank_chunk, 1), bh, kb);   // key block 0 sweeps the most stages: first
+  else map_block(blockIdx.x, BH, nkb, bh, kb);
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * 4u;
@@ -104,8 +109,10 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   const int ds_wr = DSB + (32 * w + r) * 4;   // this lane's key column of the dS image; row acc_row(i, h)
   const int dq_voff = ((16 * qb + 4 * g4) * ld + 16 * db + i16) * 4;
 
-  const int nqi = N / QS;
-  stage_load(0);
+  // CAUSAL: the sweep starts at the block's own queries; in diagonal stage j = qi - 8 kb < 8 (queries 32 j .. 32 j + 31 of the block)
+  // waves w > j see masked keys only and sit the stage out, wave j masks above its diagonal, and dQ sums the 32 (j + 1) live keys
+  const int nqi = N / QS, qi0 = CAUSAL ? kb * (OP32_BK / QS) : 0;
+  stage_load(qi0);
   stage_store(smem);
   __syncthreads();
 
@@ -115,54 +122,73 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
     if (more) stage_load(qi + 1);
     lds_char* tq = smem + PAR * STG;
     lds_char* tdo = tq + TB;
-    f32x16 nl16, nd16, s, dp;
+    const int j = CAUSAL ? qi - qi0 : 8;
+    if (!CAUSAL || w <= j) {
+      f32x16 nl16, nd16, s, dp;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 a = *FA_LDS(f32x4, tq + 2 * TB + 16 * h + 32 * g);
-      const f32x4 b = *FA_LDS(f32x4, tq + 2 * TB + 4 * QS + 16 * h + 32 * g);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a = *FA_LDS(f32x4, tq + 2 * TB + 16 * h + 32 * g);
+        const f32x4 b = *FA_LDS(f32x4, tq + 2 * TB + 4 * QS + 16 * h + 32 * g);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        nl16[4 * g + i] = a[i];
-        nd16[4 * g + i] = b[i];
+        for (int i = 0; i < 4; ++i) {
+          nl16[4 * g + i] = a[i];
+          nd16[4 * g + i] = b[i];
+        }
       }
-    }
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const frag aq = A::template row_frag<D>(tq, ra, 0, kc);
-      const frag ado = A::template row_frag<D>(tdo, ra, 0, kc);
-      const frag kfr = A::template row_frag<D>(smem + KIMG, ra, 32 * w, kc);
-      if (kc == 0) {   // row constants ride in as accumulator inputs: S' = S - L/tau, dP' = dP - delta
-        A::mma_c(s, aq, kfr, nl16);
-        A::mma_c(dp, ado, vf[kc], nd16);
-      } else {
-        A::mma(s, aq, kfr);
-        A::mma(dp, ado, vf[kc]);
+      for (int kc = 0; kc < KC; ++kc) {
+        const frag aq = A::template row_frag<D>(tq, ra, 0, kc);
+        const frag ado = A::template row_frag<D>(tdo, ra, 0, kc);
+        const frag kfr = A::template row_frag<D>(smem + KIMG, ra, 32 * w, kc);
+        if (kc == 0) {   // row constants ride in as accumulator inputs: S' = S - L/tau, dP' = dP - delta
+          A::mma_c(s, aq, kfr, nl16);
+          A::mma_c(dp, ado, vf[kc], nd16);
+        } else {
+          A::mma(s, aq, kfr);
+          A::mma(dp, ado, vf[kc]);
+        }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      s[i] = __builtin_amdgcn_exp2f(s[i] * c);
-      dp[i] = s[i] * dp[i];
-    }
+      for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] * c);
+      if (CAUSAL && w == j) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) *FA_LDS(float, smem + ds_wr + acc_row(i, h) * OP32_DSROW * 4) = dp[i];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        A::mma(acc_dv[dt], A::template tr_frag<D>(tdo, ta, 16 * s2, dt), A::pack(s, s2));
-        A::mma(acc_dk[dt], A::template tr_frag<D>(tq, ta, 16 * s2, dt), A::pack(dp, s2));
+        for (int i = 0; i < 16; ++i) s[i] = r <= acc_row(i, h) ? s[i] : 0.0f;
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dp[i] = s[i] * dp[i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *FA_LDS(float, smem + ds_wr + acc_row(i, h) * OP32_DSROW * 4) = dp[i];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          A::mma(acc_dv[dt], A::template tr_frag<D>(tdo, ta, 16 * s2, dt), A::pack(s, s2));
+          A::mma(acc_dk[dt], A::template tr_frag<D>(tq, ta, 16 * s2, dt), A::pack(dp, s2));
+        }
+    }
     __syncthreads();   // the stage's dS image is complete
     f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!CAUSAL) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {   // (two halves: the K image's 128-row offset does not fit the instruction's 16-bit immediate)
-      const int kr = k_rd + half * 128 * (D + 4) * 4, dr = ds_rd + half * 128 * 4;
+      for (int half = 0; half < 2; ++half) {   // (two halves: the K image's 128-row offset does not fit the instruction's 16-bit immediate)
+        const int kr = k_rd + half * 128 * (D + 4) * 4, dr = ds_rd + half * 128 * 4;
 #pragma unroll
-      for (int st = 0; st < 32; ++st) {
-        const float a = *FA_LDS(float, smem + dr + 16 * st);
-        const float b = *FA_LDS(float, smem + kr + st * 4 * (D + 4) * 4);
-        t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t4, 0, 0, 0);
+        for (int st = 0; st < 32; ++st) {
+          const float a = *FA_LDS(float, smem + dr + 16 * st);
+          const float b = *FA_LDS(float, smem + kr + st * 4 * (D + 4) * 4);
+          t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t4, 0, 0, 0);
+        }
+      }
+    } else {
+      const int ng = min(8, j + 1);   // 32-key groups at or below the stage's diagonal
+      for (int g = 0; g < ng; ++g) {
+        const int kr = k_rd + g * 32 * (D + 4) * 4, dr = ds_rd + g * 32 * 4;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const float a = *FA_LDS(float, smem + dr + 16 * st);
+          const float b = *FA_LDS(float, smem + kr + st * 4 * (D + 4) * 4);
+          t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t4, 0, 0, 0);
+        }
       }
     }
     const int soff = qi * QS * ld * 4;
@@ -171,7 +197,7 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
     if (more) stage_store(smem + (PAR ^ 1) * STG);
     __syncthreads();   // the next stage is published; every wave is done with this stage's dS image
   };
-  int qi = 0;
+  int qi = qi0;
   for (; qi + 1 < nqi; qi += 2) {
     slice(ic<0>{}, qi);
     slice(ic<1>{}, qi + 1);

@@ -92,9 +92,9 @@ int fa_mi355x_fwd(const void* q, const void* k, const void* v, float* out, float
 size_t fa_mi355x_bwd_workspace_bytes(int batch, int N, int d);
 
 /* The same for a backward call with per-call options (fa_mi355x_bwd_ex).  Product library: fa_mi355x_bwd_workspace_bytes.  Diagnostic
- * library: opts[4] = 3 (the chained one-pass backward) adds a 4-KiB header and, when its chains do not cover whole heads (batch < CUs),
- * one slab of N * 64 floats per workgroup: batch * nchains * N * 256 bytes with nchains = the smallest divisor of N / 256 that gives
- * batch * nchains >= CUs (256 MiB at batch 64, N 4096 on 256 CUs). */
+ * library: opts[4] = 3 (the chained one-pass backward) adds a 4-KiB header and, when a chain is more than one key block (nchains <
+ * N / 256), one slab of N * 64 floats per workgroup: batch * nchains * N * 256 bytes with nchains = the smallest divisor of N / 256
+ * that gives batch * nchains >= CUs (256 MiB at batch 64, N 4096 on 256 CUs). */
 size_t fa_mi355x_bwd_workspace_bytes_ex(int batch, int N, int d, const int* opts, int nopts);
 
 /* Product library: a no-op that sets *status = 0 (no kernel of it waits for another workgroup, and backward calls may run

@@ -206,23 +206,24 @@ def test_c2_fa1_forward_backward_fp32_full(ops, causal):
 
 @pytest.mark.parametrize("N", [256, 512, 1280])
 @pytest.mark.parametrize("bnhd", [False, True])
-def test_fp32_one_pass_backward(dev, N, bnhd):
-    """fp32, d = 64, non-causal, N a multiple of 256: the default backward is ONE kernel (bwd_onepass_f32_kernel: the reference's five
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp32_one_pass_backward(dev, N, bnhd, causal):
+    """fp32, d = 64, N a multiple of 256: the default backward is ONE kernel (bwd_onepass_f32_kernel: the reference's five
     products, src/flash_attn2_bw.cu:94-247, dQ by fp32 atomics into a q_grad the LIBRARY zero-fills).  Against the fp64 oracle at the
     fp32 tolerance, against the two-kernel path (option 4 = 4: dk, dv bitwise -- the same per-key arithmetic -- and dq to summation
-    order), both layouts and both side-output conventions, on gradient buffers that hold NaN on entry."""
+    order), both layouts and both side-output conventions, with and without the causal mask (diagonal stages: idle waves, the masked wave, the
+    shortened dQ sum), on gradient buffers that hold NaN on entry."""
     import torch
     from flash_attention_minitorch_amd import _lib
     B, H, d = 2, 3, 64
-    names = _lib.plan(B * H, N, d, False, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, None)
+    names = _lib.plan(B * H, N, d, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, None)
     assert names == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"], names
-    two = _lib.plan(B * H, N, d, False, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, (0, 0, 0, 0, 4))
+    two = _lib.plan(B * H, N, d, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, (0, 0, 0, 0, 4))
     assert "bwd_onepass_f32_kernel" not in two and len(two) >= 2, two
-    assert "bwd_onepass_f32_kernel" not in _lib.plan(B * H, N, d, True, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, None)
     assert "bwd_onepass_f32_kernel" not in _lib.plan(B * H, N + 8, d, False, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, None)
     rng = np.random.default_rng(77 + N)
     arrs = [rand_u(rng, (B * H, N, d)) for _ in range(4)]
-    ref = oracle_heads(*arrs, False, range(B * H))
+    ref = oracle_heads(*arrs, causal, range(B * H))
     t4 = [torch.from_numpy(a).to("cuda").view(B, H, N, d) for a in arrs]
     if bnhd:
         q, k, v, do = (t.permute(0, 2, 1, 3).contiguous() for t in t4)
@@ -232,14 +233,14 @@ def test_fp32_one_pass_backward(dev, N, bnhd):
         back = to_np
     for variant in (_lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2):
         if bnhd:
-            o, l, m = dev.flash_attn_fwd_bnhd(q, k, v, False, variant)
-            g1 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, False, variant)
-            g2 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, False, variant, opts=(0, 0, 0, 0, 4))
+            o, l, m = dev.flash_attn_fwd_bnhd(q, k, v, causal, variant)
+            g1 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant)
+            g2 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant, opts=(0, 0, 0, 0, 4))
         else:
-            o, l, m = dev.flash_attn_fwd(q, k, v, False, variant)
+            o, l, m = dev.flash_attn_fwd(q, k, v, causal, variant)
             nan = lambda: tuple(torch.full(q.shape, float("nan"), dtype=torch.float32, device="cuda") for _ in range(3))
-            g1 = dev.flash_attn_bwd(q, k, v, o, do, l, m, False, variant, grads=nan())
-            g2 = dev.flash_attn_bwd(q, k, v, o, do, l, m, False, variant, grads=nan(), opts=(0, 0, 0, 0, 4))
+            g1 = dev.flash_attn_bwd(q, k, v, o, do, l, m, causal, variant, grads=nan())
+            g2 = dev.flash_attn_bwd(q, k, v, o, do, l, m, causal, variant, grads=nan(), opts=(0, 0, 0, 0, 4))
         for nm, a, b in zip(("dq", "dk", "dv"), g1, g2):
             assert maxabs(back(a), ref[nm]) < TOL32, (nm, variant)
             if nm == "dq":

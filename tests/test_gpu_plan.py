@@ -60,4 +60,8 @@ def test_plan_of_option_and_feature_paths():
     # a ragged causal launch: phased kernels, each followed by its split-operand launch for the rows with few keys
     assert _lib.plan(2, 200, 128, True, fa2, bf, 0) == ["fwd_kernel", "fwd_kernel"]
     # fp32 (the reference's own dtype)
-    assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, _lib.FA_DTYPE_F32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
+    f32 = _lib.FA_DTYPE_F32
+    assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]   # d = 64, N % 256 == 0
+    assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, f32, 7, (0, 0, 0, 0, 4)) == ["bwd_prep_kernel", "bwd_dkdv_kernel", "bwd_dq_kernel"]
+    assert _lib.plan(64, 2000, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
+    assert _lib.plan(64, 2048, 32, False, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]

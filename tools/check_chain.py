@@ -89,7 +89,7 @@ if __name__ == "__main__":
     good &= run(1, 20, 768, seed=4, heads=[0, 7, 19])
     good &= run(8, 8, 4096, seed=5, heads=[0, 13, 63])     # the metric shape: 4 chains of 4 blocks
     good &= run(3, 7, 2048, seed=6, heads=[0, 20])
-    good &= run(32, 8, 1024, seed=7, heads=[0, 100, 255])  # a whole head per workgroup: dq carries the sums, no atomics
+    good &= run(32, 8, 1024, seed=7, heads=[0, 100, 255])  # a whole head per workgroup: sums in the slab, plain final store, no atomics
     good &= run(16, 8, 2048, seed=8, heads=[3, 127])       # two chains of four
     print("ALL OK" if good else "SOME FAILED", flush=True)
     if "--time" in sys.argv:

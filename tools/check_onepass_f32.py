@@ -16,18 +16,18 @@ from flash_attention_minitorch_amd import _lib, device_ops  # noqa: E402
 TWO = (0, 0, 0, 0, 4)
 
 
-def run(B, H, N, d=64, seed=0, heads=None, scale=1.0, variant=None):
+def run(B, H, N, d=64, seed=0, heads=None, scale=1.0, variant=None, causal=False):
     rng = np.random.default_rng(seed)
     qf, kf, vf, dof = ((scale * rng.uniform(-1, 1, (B * H, N, d))).astype(np.float32) for _ in range(4))
     tq, tk, tv, tdo = (torch.from_numpy(a).to("cuda") for a in (qf, kf, vf, dof))
     variant = _lib.FA_VARIANT_FA2 if variant is None else variant
-    o, L, M = device_ops.flash_attn_fwd(tq, tk, tv, False, variant)
-    g2 = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, False, variant, opts=TWO)]
-    g1 = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, False, variant)]
-    g1b = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, False, variant)]
+    o, L, M = device_ops.flash_attn_fwd(tq, tk, tv, causal, variant)
+    g2 = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, causal, variant, opts=TWO)]
+    g1 = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, causal, variant)]
+    g1b = [t.clone() for t in device_ops.flash_attn_bwd(tq, tk, tv, o, tdo, L, M, causal, variant)]
     torch.cuda.synchronize()
     names = ("dq", "dk", "dv")
-    msg = [f"B{B} H{H} N{N} v{variant}"]
+    msg = [f"B{B} H{H} N{N} v{variant}{' causal' if causal else ''}"]
     ok = True
     for n_, a, b, c in zip(names, g1, g2, g1b):
         dsplit = float((a - b).abs().max())
@@ -37,7 +37,7 @@ def run(B, H, N, d=64, seed=0, heads=None, scale=1.0, variant=None):
     hs = range(B * H) if heads is None else heads
     worst = 0.0
     for hh in hs:
-        refs = oracle.dense_attention_bw(qf[hh:hh + 1], kf[hh:hh + 1], vf[hh:hh + 1], dof[hh:hh + 1])
+        refs = oracle.dense_attention_bw(qf[hh:hh + 1], kf[hh:hh + 1], vf[hh:hh + 1], dof[hh:hh + 1], causal)
         for n_, a, ref in zip(names, g1, refs):
             e = float(np.max(np.abs(a[hh].cpu().numpy() - ref[0])))
             worst = max(worst, e)
@@ -49,27 +49,27 @@ def run(B, H, N, d=64, seed=0, heads=None, scale=1.0, variant=None):
     return ok
 
 
-def timeit(B, H, N, d=64, iters=20):
+def timeit(B, H, N, d=64, iters=20, causal=False):
     gen = torch.Generator(device="cuda").manual_seed(1)
     mk = lambda: (torch.rand((B * H, N, d), device="cuda", generator=gen) - 0.5) * 2
     q, k, v, do = mk(), mk(), mk(), mk()
-    o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal=False)
+    o, L, _ = device_ops.flash_attn_fwd(q, k, v, causal=causal)
     ws = device_ops.bwd_workspace(q)
     grads = tuple(torch.empty((B * H, N, d), dtype=torch.float32, device="cuda") for _ in range(3))
     res = {}
     for name, opts in (("two", TWO), ("one", None), ("two2", TWO), ("one2", None)):
         for _ in range(5):
-            device_ops.flash_attn_bwd(q, k, v, o, do, L, workspace=ws, grads=grads, opts=opts)
+            device_ops.flash_attn_bwd(q, k, v, o, do, L, causal=causal, workspace=ws, grads=grads, opts=opts)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            device_ops.flash_attn_bwd(q, k, v, o, do, L, workspace=ws, grads=grads, opts=opts)
+            device_ops.flash_attn_bwd(q, k, v, o, do, L, causal=causal, workspace=ws, grads=grads, opts=opts)
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / iters
-    fl = 10.0 * B * H * N * N * d
-    print(f"time B{B} H{H} N{N}: " + "  ".join(f"{k}={v:.4f} ms ({fl / v / 1e9:.1f} TF/s)" for k, v in res.items()), flush=True)
+    fl = 10.0 * B * H * N * N * d * (0.5 if causal else 1.0)
+    print(f"time B{B} H{H} N{N}{' causal' if causal else ''}: " + "  ".join(f"{k}={v:.4f} ms ({fl / v / 1e9:.1f} TF/s)" for k, v in res.items()), flush=True)
 
 
 if __name__ == "__main__":
@@ -82,6 +82,11 @@ if __name__ == "__main__":
     good &= run(8, 8, 2048, seed=6, heads=[0, 63])         # configs[2]
     good &= run(8, 8, 2048, seed=6, heads=[5], variant=_lib.FA_VARIANT_FA1)
     good &= run(3, 7, 1280, seed=7, heads=[0, 20], scale=3.0)
+    for c_args in ((1, 1, 256), (1, 2, 512), (2, 3, 1024), (1, 20, 768)):
+        good &= run(*c_args, seed=11, causal=True)
+    good &= run(8, 8, 2048, seed=12, heads=[0, 63], causal=True)     # the reference's timing harness shape
+    good &= run(8, 8, 2048, seed=12, heads=[9], causal=True, variant=_lib.FA_VARIANT_FA1)
+    good &= run(3, 7, 1280, seed=13, heads=[0, 20], scale=3.0, causal=True)
     print("ALL OK" if good else "SOME FAILED", flush=True)
     if "--time" in sys.argv:
         timeit(8, 8, 1024)
@@ -89,4 +94,8 @@ if __name__ == "__main__":
         timeit(8, 8, 4096)
         timeit(32, 8, 1024)
         timeit(2, 8, 8192)
+        timeit(8, 8, 1024, causal=True)
+        timeit(8, 8, 2048, causal=True)
+        timeit(8, 8, 4096, causal=True)
+        timeit(32, 8, 2048, causal=True)
     sys.exit(0 if good else 1)
