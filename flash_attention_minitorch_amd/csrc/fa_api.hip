@@ -463,14 +463,13 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
 // which reads the workspace the dQ launch wrote)?  Yes whenever dq_stage sends the call to a plain main build: not under a key mask
 // or dropout, not bf16 with N < 64 (split-operand builds), not the bf16 d = 64 slot build with masked periods (no registers), not a
 // diagnostic build; option 4 = 1 keeps the separate preprocess kernel (A/B), 2 is the one-pass backward.
-// fp32, d = 64, N a multiple of 256, no key mask / dropout, dQ and dK/dV asked for together: the one-pass backward
+// fp32, d = 64, N >= 256, no key mask / dropout, dQ and dK/dV asked for together: the one-pass backward
 // (fa_bwd_onepass_f32.h: five products instead of the two-kernel path's seven, dQ by fp32 atomics).  Option 4 = 4 keeps two kernels
 // (dq bitwise repeatable from run to run).
 template <typename T, int D>
 bool onepass_f32(int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
   const int both = FA_BWD_STAGE_DKDV | FA_BWD_STAGE_DQ;
-  return sizeof(T) == 4 && D == 64 && (stages & both) == both && tun.v[4] == 0 && !lay.kmask && !lay.drop_thr && N >= 256 &&
-         N % 256 == 0;
+  return sizeof(T) == 4 && D == 64 && (stages & both) == both && tun.v[4] == 0 && !lay.kmask && !lay.drop_thr && N >= 256;
 }
 
 template <typename T, int D>
@@ -576,15 +575,17 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
       // the workgroups ADD into dq (the reference's caller zeroes q_grad for its atomicAdd as well: minitorch/cuda_kernel_ops.py:609-611);
       // [B][N][H][d] or [BH][N][d]: the tensor is one contiguous range either way
       if (!t_probe && !t_plan) FA_HIP_TRY(hipMemsetAsync(dq, 0, (size_t)rows * D * sizeof(float), st));
-      const int nkb = N / 256;
-      if (causal) {   // key block 0 (the longest sweep) of a chunk of heads first
-        lay.rank_chunk = rank_chunk(1, nkb);
-        FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, true>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q,
-                  (const float*)k, (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau);
+      const int nkb = (N + 255) / 256;
+      if (causal) lay.rank_chunk = rank_chunk(1, nkb);   // key block 0 (the longest sweep) of a chunk of heads first
+#define FA_ONEPASS(C, R)                                                                                                             \
+  FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, C, R>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q, (const float*)k, \
+            (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau)
+      if (N % 256 == 0) {
+        if (causal) FA_ONEPASS(true, false); else FA_ONEPASS(false, false);
       } else {
-        FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, false>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q,
-                  (const float*)k, (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau);
+        if (causal) FA_ONEPASS(true, true); else FA_ONEPASS(false, true);
       }
+#undef FA_ONEPASS
       FA_HIP_TRY(hipGetLastError());
       return FA_OK;
     }

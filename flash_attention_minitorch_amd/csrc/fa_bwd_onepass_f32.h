@@ -1,4 +1,4 @@
-// FlashAttention backward for MI355X (gfx950), fp32 (the reference's own dtype), d = 64, N a multiple of 256: ONE pass for
+// FlashAttention backward for MI355X (gfx950), fp32 (the reference's own dtype), d = 64, N >= 256: ONE pass for
 // dQ, dK and dV -- the five products of the reference's single-pass FA-2 backward (src/flash_attn2_bw.cu:94-247: S, dP, dV, dK, dQ),
 // dQ summed over the key blocks with fp32 atomics as the reference does (:228).  Part of the kernel set described in fa_kernels.h.
 //
@@ -33,7 +33,7 @@ constexpr int OP32_DSROW = OP32_BK + 4;                           // floats per 
 constexpr int OP32_DS = OP32_QS * OP32_DSROW * 4;
 constexpr int OP32_SMEM = 2 * OP32_STG + OP32_KIMG + OP32_DS;     // 138,240 B: one workgroup per CU, two waves per SIMD
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool RAGGED>
 __global__ void __launch_bounds__(512, 2)
 bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                        const float* __restrict__ dout, const float* __restrict__ nlc, const float* __restrict__ ndelta,
@@ -70,6 +70,11 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
     TileStager<float, D, OP32_BK, 512> sk;
     sk.init(tid, ld);
     sk.load(krs, kb0);
+    if (RAGGED && kb0 + OP32_BK > N) {   // ragged N: key rows past N as exact zeros (dS is zero there; 0 * whatever lies behind the tensor must be too)
+#pragma unroll
+      for (int i = 0; i < sk.PER; ++i)
+        if (kb0 + tid / sk.CPR + i * sk.RSTEP >= N) sk.regs[i] = u32x4{0u, 0u, 0u, 0u};
+    }
     sk.store(smem + KIMG);
   }
   f32x16 acc_dk[DT], acc_dv[DT];
@@ -87,9 +92,11 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   auto stage_load = [&](int qi) {
     sq.load(qrs, qi * QS);
     sdo.load(dors, qi * QS);
-    if (tid < QS) {
-      st_nl = nlg[qi * QS + tid];
-      st_de = deg[qi * QS + tid];
+    if (RAGGED && (qi + 1) * QS > N && qi * QS + tid / sq.CPR >= N) sq.regs[0] = sdo.regs[0] = u32x4{0u, 0u, 0u, 0u};   // (one chunk per thread)
+    if (tid < QS) {   // (rows past a ragged N: P = exp2(c * (0 - 1e30)) = 0, so nothing of them reaches dK, dV)
+      const bool in = !RAGGED || qi * QS + tid < N;
+      st_nl = in ? nlg[qi * QS + tid] : -1e30f;
+      st_de = in ? deg[qi * QS + tid] : 0.0f;
     }
   };
   auto stage_store = [&](lds_char* b) {
@@ -111,7 +118,10 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
 
   // CAUSAL: the sweep starts at the block's own queries; in diagonal stage j = qi - 8 kb < 8 (queries 32 j .. 32 j + 31 of the block)
   // waves w > j see masked keys only and sit the stage out, wave j masks above its diagonal, and dQ sums the 32 (j + 1) live keys
-  const int nqi = N / QS, qi0 = CAUSAL ? kb * (OP32_BK / QS) : 0;
+  // RAGGED (N not a multiple of 256; its own build: the checks cost the aligned one 4-6 %): rows past N are staged as zeros (Q, dO, K; V by its resource's range check); the last key block clears P at its keys >= N,
+  // the last stage skips the adds of its rows >= N, the epilogue the stores of its keys >= N.
+  const int nqi = (N + QS - 1) / QS, qi0 = CAUSAL ? kb * (OP32_BK / QS) : 0;
+  const bool ragged_keys = RAGGED && kw0 + 32 > N;   // (wave-uniform)
   stage_load(qi0);
   stage_store(smem);
   __syncthreads();
@@ -154,6 +164,11 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = r <= acc_row(i, h) ? s[i] : 0.0f;
       }
+      if (ragged_keys) {
+        const bool keep = kw0 + r < N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = keep ? s[i] : 0.0f;
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) dp[i] = s[i] * dp[i];
 #pragma unroll
@@ -192,8 +207,15 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
       }
     }
     const int soff = qi * QS * ld * 4;
+    if (!RAGGED || (qi + 1) * QS <= N) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(t4[j] * tau, dqrs, dq_voff, soff + j * ld * 4, 0);
+      for (int jj = 0; jj < 4; ++jj) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(t4[jj] * tau, dqrs, dq_voff, soff + jj * ld * 4, 0);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (qi * QS + 16 * qb + 4 * g4 + jj < N)
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(t4[jj] * tau, dqrs, dq_voff, soff + jj * ld * 4, 0);
+    }
     if (more) stage_store(smem + (PAR ^ 1) * STG);
     __syncthreads();   // the next stage is published; every wave is done with this stage's dS image
   };
@@ -204,6 +226,7 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   }
   if (qi < nqi) slice(ic<0>{}, qi);
 
+  if (RAGGED && kw0 + r >= N) return;
   float* dkrow = dk + base + (size_t)(kw0 + r) * ld;
   float* dvrow = dv + base + (size_t)(kw0 + r) * ld;
 #pragma unroll

@@ -131,8 +131,8 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[3]  (diagnostic library only)
  *   opts[4]  1 = keep the separate preprocess kernel (default: the dQ launch preprocesses its own rows, writes the workspace and runs
  *            BEFORE the dK/dV launch; same results up to summation order of delta);
- *            4 = fp32, d = 64: two kernels where the ONE-PASS backward would run.  By default an fp32, d = 64, non-causal backward with N a
- *            multiple of 256 and no key mask / dropout, asked for dQ and dK/dV together, runs bwd_onepass_f32_kernel: the five products of
+ *            4 = fp32, d = 64: two kernels where the ONE-PASS backward would run.  By default an fp32, d = 64 backward with N >= 256 and
+ *            no key mask / dropout, asked for dQ and dK/dV together, runs bwd_onepass_f32_kernel: the five products of
  *            src/flash_attn2_bw.cu:94-247 in one key-stationary pass, dQ added to the (library zero-filled) q_grad with fp32 atomics as
  *            the reference does at :228 -- 131 vs 98.5 TFLOP/s at BASELINE configs[2] because the exact-fp32 MFMA bounds it, not the
  *            atomics.  dq then differs from run to run in the last bits (order of the N/256 adds per element; dk, dv are bitwise

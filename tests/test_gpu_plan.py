@@ -61,7 +61,8 @@ def test_plan_of_option_and_feature_paths():
     assert _lib.plan(2, 200, 128, True, fa2, bf, 0) == ["fwd_kernel", "fwd_kernel"]
     # fp32 (the reference's own dtype)
     f32 = _lib.FA_DTYPE_F32
-    assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]   # d = 64, N % 256 == 0
+    assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]   # d = 64, N >= 256
+    assert _lib.plan(64, 2000, 64, False, _lib.FA_VARIANT_FA2, f32, 7) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]
     assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, f32, 7, (0, 0, 0, 0, 4)) == ["bwd_prep_kernel", "bwd_dkdv_kernel", "bwd_dq_kernel"]
-    assert _lib.plan(64, 2000, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
+    assert _lib.plan(64, 200, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
     assert _lib.plan(64, 2048, 32, False, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU check of the fp32 one-pass backward (bwd_onepass_f32_kernel: the default for fp32, d = 64, non-causal, N % 256 == 0) against
+"""GPU check of the fp32 one-pass backward (bwd_onepass_f32_kernel: the default for fp32, d = 64, N >= 256) against
 the fp64 oracle and the two-kernel backward (option 4 = 4), plus timing of both.
 usage: python tools/check_onepass_f32.py [--time]"""
 import os
@@ -82,6 +82,9 @@ if __name__ == "__main__":
     good &= run(8, 8, 2048, seed=6, heads=[0, 63])         # configs[2]
     good &= run(8, 8, 2048, seed=6, heads=[5], variant=_lib.FA_VARIANT_FA1)
     good &= run(3, 7, 1280, seed=7, heads=[0, 20], scale=3.0)
+    for r_args in ((1, 2, 257), (2, 3, 300), (1, 5, 1000), (3, 2, 511), (2, 2, 2017)):   # ragged last key block / last stage
+        good &= run(*r_args, seed=21)
+        good &= run(*r_args, seed=22, causal=True)
     for c_args in ((1, 1, 256), (1, 2, 512), (2, 3, 1024), (1, 20, 768)):
         good &= run(*c_args, seed=11, causal=True)
     good &= run(8, 8, 2048, seed=12, heads=[0, 63], causal=True)     # the reference's timing harness shape
@@ -98,4 +101,6 @@ if __name__ == "__main__":
         timeit(8, 8, 2048, causal=True)
         timeit(8, 8, 4096, causal=True)
         timeit(32, 8, 2048, causal=True)
+        timeit(8, 8, 2000)
+        timeit(8, 8, 2000, causal=True)
     sys.exit(0 if good else 1)
