@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""A/B of two builds of the core library in ONE process on one device (box-to-box spread is larger than most kernel changes):
+library A = the in-tree product build, library B = another build of csrc/fa_api.hip (e.g. with a -D switch), both loaded with ctypes
+and timed alternately on the same tensors through fa_mi355x_fwd_ex / fa_mi355x_bwd_stages_ex-free entry points.
+usage: python tools/ab_two_libs.py path/to/libB.so [fwd|bwd] [causal]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flash_attention_minitorch_amd import _lib, device_ops  # noqa: E402
+
+
+def load(path):
+    lib = ctypes.CDLL(path)
+    src = _lib.core()
+    for name in ("fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex"):
+        f, g = getattr(lib, name), getattr(src, name)
+        f.argtypes, f.restype = g.argtypes, g.restype
+    return lib
+
+
+def main():
+    libs = {"A": _lib.core(), "B": load(sys.argv[1])}
+    what = sys.argv[2] if len(sys.argv) > 2 else "fwd"
+    causal = int(len(sys.argv) > 3 and sys.argv[3] == "causal")
+    B, H, N, d = 8, 8, 4096, 64
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda: ((torch.rand((B * H, N, d), device="cuda", generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    o = torch.empty((B * H, N, d), dtype=torch.float32, device="cuda")
+    L = torch.empty((B * H, N), dtype=torch.float32, device="cuda")
+    grads = [torch.empty_like(o) for _ in range(3)]
+    ws = device_ops.bwd_workspace(q)
+    arr, cnt = _lib.opts_array(device_ops.OPTS_FOLDED_SCALE)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd(lib):
+        rc = lib.fa_mi355x_fwd_ex(p(q), p(k), p(v), p(o), p(L), None, B * H, N, d, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_BF16, arr, cnt, st)
+        assert rc == 0, rc
+
+    def bwd(lib):
+        rc = lib.fa_mi355x_bwd_ex(p(q), p(k), p(v), p(o), p(do), p(grads[0]), p(grads[1]), p(grads[2]), p(L), None, p(ws), B * H, N, d,
+                                  causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_BF16, device_ops.STAGE_ALL, arr, cnt, st)
+        assert rc == 0, rc
+
+    fwd(libs["A"])
+    fn = fwd if what == "fwd" else bwd
+    res = {"A": [], "B": []}
+    for rnd in range(6):
+        for name in ("A", "B"):
+            for _ in range(10):
+                fn(libs[name])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                fn(libs[name])
+            e1.record()
+            torch.cuda.synchronize()
+            res[name].append(e0.elapsed_time(e1) / 50)
+    for name in ("A", "B"):
+        r = res[name]
+        print(f"{what} {'causal ' if causal else ''}{name}: " + " ".join(f"{x:.4f}" for x in r) + f"  | median of last 4 = {sorted(r[2:])[1]:.4f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
