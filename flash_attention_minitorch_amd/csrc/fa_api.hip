@@ -107,7 +107,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
 #ifndef FA_DIAG
   // (round 3 library diet: the values that lost their A/B and had no test -- opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1,
   // opts[4] = 2 (the one-pass backward), opts[6] = 1 -- exist in the diagnostic build only, together with their kernels)
-  static const int allowed[NTUN][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, 4, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1},
+  static const int allowed[NTUN][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, 4, 5, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1},
                                        {0, 1, 2, 3, -1}, {0, 1, -1}};
   for (int i = 0; i < NTUN; ++i) {
     bool ok = false;
@@ -464,18 +464,26 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
 // or dropout, not bf16 with N < 64 (split-operand builds), not the bf16 d = 64 slot build with masked periods (no registers), not a
 // diagnostic build; option 4 = 1 keeps the separate preprocess kernel (A/B), 2 is the one-pass backward.
 // fp32, d = 64, N >= 256, no key mask / dropout, dQ and dK/dV asked for together: the one-pass backward
-// (fa_bwd_onepass_f32.h: five products instead of the two-kernel path's seven, dQ by fp32 atomics).  Option 4 = 4 keeps two kernels
-// (dq bitwise repeatable from run to run).
+// (fa_bwd_onepass_f32.h: five products instead of the two-kernel path's seven, dQ by fp32 atomics) when its launch fills the chip:
+// one 8-wave workgroup per CU and 256-key block, so batch * ceil(N / 256) workgroups run in ceil(that / CUs) rounds; it takes the
+// call when the last round is full enough that 7/5 of the work on finer workgroups would be slower (measured, profiles/
+// r04_onepass_f32.txt: 128 workgroups 0.64 vs 0.49 ms, 256 workgroups 0.18 vs 0.24).  Option 4: 4 = two kernels always (dq bitwise
+// repeatable from run to run), 5 = one pass whatever the launch size.
 template <typename T, int D>
-bool onepass_f32(int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
+bool onepass_f32(int batch, int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
   const int both = FA_BWD_STAGE_DKDV | FA_BWD_STAGE_DQ;
-  return sizeof(T) == 4 && D == 64 && (stages & both) == both && tun.v[4] == 0 && !lay.kmask && !lay.drop_thr && N >= 256;
+  if (!(sizeof(T) == 4 && D == 64 && (stages & both) == both && (tun.v[4] == 0 || tun.v[4] == 5) && !lay.kmask && !lay.drop_thr &&
+        N >= 256))
+    return false;
+  if (tun.v[4] == 5) return true;
+  const long cus = device_cus() > 0 ? device_cus() : 256, wgs = (long)batch * ((N + 255) / 256), rounds = (wgs + cus - 1) / cus;
+  return 5 * wgs >= 4 * rounds * cus;   // the launch's rounds are at least 80 % full
 }
 
 template <typename T, int D>
 bool dq_fuses_prep(int batch, int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
   constexpr bool BF = sizeof(T) == 2;
-  if (onepass_f32<T, D>(N, lay, causal, stages, tun)) return false;
+  if (onepass_f32<T, D>(batch, N, lay, causal, stages, tun)) return false;
   const int need = FA_BWD_STAGE_PREP | FA_BWD_STAGE_DQ;
   if ((stages & need) != need || tun.v[4] != 0 || lay.kmask || lay.drop_thr || (BF && N < 64) || tun.v[2] > 4) return false;
   if constexpr (BF && D == 64) {
@@ -571,7 +579,7 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     if (rc) return rc;
   }
   if constexpr (sizeof(T) == 4 && D == 64) {
-    if (onepass_f32<T, D>(N, lay, causal, stages, tun)) {
+    if (onepass_f32<T, D>(batch, N, lay, causal, stages, tun)) {
       // the workgroups ADD into dq (the reference's caller zeroes q_grad for its atomicAdd as well: minitorch/cuda_kernel_ops.py:609-611);
       // [B][N][H][d] or [BH][N][d]: the tensor is one contiguous range either way
       if (!t_probe && !t_plan) FA_HIP_TRY(hipMemsetAsync(dq, 0, (size_t)rows * D * sizeof(float), st));

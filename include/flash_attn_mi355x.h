@@ -131,17 +131,14 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[3]  (diagnostic library only)
  *   opts[4]  1 = keep the separate preprocess kernel (default: the dQ launch preprocesses its own rows, writes the workspace and runs
  *            BEFORE the dK/dV launch; same results up to summation order of delta);
- *            4 = fp32, d = 64: two kernels where the ONE-PASS backward would run.  By default an fp32, d = 64 backward with N >= 256 and
- *            no key mask / dropout, asked for dQ and dK/dV together, runs bwd_onepass_f32_kernel: the five products of
+ *            4 / 5 = fp32, d = 64: two kernels always / the ONE-PASS backward whatever the launch size.  By default an fp32, d = 64
+ *            backward with N >= 256 and no key mask / dropout, asked for dQ and dK/dV together, runs bwd_onepass_f32_kernel when its
+ *            launch -- batch * ceil(N / 256) workgroups, one per CU -- runs in rounds that are at least 80 % full: the five products of
  *            src/flash_attn2_bw.cu:94-247 in one key-stationary pass, dQ added to the (library zero-filled) q_grad with fp32 atomics as
  *            the reference does at :228 -- 131 vs 98.5 TFLOP/s at BASELINE configs[2] because the exact-fp32 MFMA bounds it, not the
- *            atomics.  dq then differs from run to run in the last bits (order of the N/256 adds per element; dk, dv are bitwise
- *            stable); 4 restores the bitwise repeatable two-kernel path;
- *            (diagnostic library only: 2 = the one-pass backward with an ordered hand-off, round 2; 3 = the CHAINED one-pass backward,
- *            round 4: bf16, d = 64, non-causal, N a multiple of 256: the five products of src/flash_attn2_bw.cu:94-247 in one
- *            key-stationary kernel, a workgroup carrying its running dQ tiles through memory along N / (256 * nchains) consecutive key
- *            blocks and, with nchains > 1, adding to a zero-filled q_grad with fp32 atomics from the last one, the reference's scheme at
- *            :228.  Both measured slower than the two-kernel default: profiles/r04_chain_backward.txt)
+ *            atomics (launches that leave CUs idle stay on the two kernels' finer workgroups: 128 workgroups 0.64 vs 0.49 ms).  dq then
+ *            differs from run to run in the last bits (order of the N/256 adds per element; dk, dv are bitwise stable); 4 restores
+ *            the bitwise repeatable two-kernel path;
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
  *            per workgroup when the launch still covers every CU), and so does the non-causal d = 64 dQ kernel (default: query block
  *            qb of several consecutive heads, same condition); bitwise the same results

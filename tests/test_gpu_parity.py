@@ -208,7 +208,7 @@ def test_c2_fa1_forward_backward_fp32_full(ops, causal):
 @pytest.mark.parametrize("bnhd", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
 def test_fp32_one_pass_backward(dev, N, bnhd, causal):
-    """fp32, d = 64, N >= 256: the default backward is ONE kernel (bwd_onepass_f32_kernel: the reference's five
+    """fp32, d = 64, N >= 256: the backward of a launch that fills the chip is ONE kernel (bwd_onepass_f32_kernel: the reference's five
     products, src/flash_attn2_bw.cu:94-247, dQ by fp32 atomics into a q_grad the LIBRARY zero-fills).  Against the fp64 oracle at the
     fp32 tolerance, against the two-kernel path (option 4 = 4: dk, dv bitwise -- the same per-key arithmetic -- and dq to summation
     order), both layouts and both side-output conventions, with and without the causal mask (diagonal stages: idle waves, the masked wave, the
@@ -216,11 +216,15 @@ def test_fp32_one_pass_backward(dev, N, bnhd, causal):
     import torch
     from flash_attention_minitorch_amd import _lib
     B, H, d = 2, 3, 64
-    names = _lib.plan(B * H, N, d, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, None)
-    assert names == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"], names
-    two = _lib.plan(B * H, N, d, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, (0, 0, 0, 0, 4))
+    ONE, TWO = (0, 0, 0, 0, 5), (0, 0, 0, 0, 4)   # (6 heads do not fill the chip: the default would take two kernels here, see below)
+    f32, fa2 = _lib.FA_DTYPE_F32, _lib.FA_VARIANT_FA2
+    assert _lib.plan(B * H, N, d, causal, fa2, f32, dev.STAGE_ALL, ONE) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]
+    two = _lib.plan(B * H, N, d, causal, fa2, f32, dev.STAGE_ALL, TWO)
     assert "bwd_onepass_f32_kernel" not in two and len(two) >= 2, two
-    assert "bwd_onepass_f32_kernel" not in _lib.plan(B * H, 200, d, False, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, dev.STAGE_ALL, None)
+    assert "bwd_onepass_f32_kernel" not in _lib.plan(B * H, 200, d, False, fa2, f32, dev.STAGE_ALL, ONE)
+    # the default takes the one-pass kernel when its launch (batch * ceil(N / 256) workgroups of one per CU) runs in rounds >= 80 % full
+    for bh, want in ((64, True), (32, True), (16, False), (40, False), (52, True), (512, True)):
+        assert ("bwd_onepass_f32_kernel" in _lib.plan(bh, 2048, d, causal, fa2, f32, dev.STAGE_ALL, None)) == want, bh
     rng = np.random.default_rng(77 + N)
     arrs = [rand_u(rng, (B * H, N, d)) for _ in range(4)]
     ref = oracle_heads(*arrs, causal, range(B * H))
@@ -234,13 +238,13 @@ def test_fp32_one_pass_backward(dev, N, bnhd, causal):
     for variant in (_lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2):
         if bnhd:
             o, l, m = dev.flash_attn_fwd_bnhd(q, k, v, causal, variant)
-            g1 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant)
-            g2 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant, opts=(0, 0, 0, 0, 4))
+            g1 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant, opts=ONE)
+            g2 = dev.flash_attn_bwd_bnhd(q, k, v, o, do, l, m, causal, variant, opts=TWO)
         else:
             o, l, m = dev.flash_attn_fwd(q, k, v, causal, variant)
             nan = lambda: tuple(torch.full(q.shape, float("nan"), dtype=torch.float32, device="cuda") for _ in range(3))
-            g1 = dev.flash_attn_bwd(q, k, v, o, do, l, m, causal, variant, grads=nan())
-            g2 = dev.flash_attn_bwd(q, k, v, o, do, l, m, causal, variant, grads=nan(), opts=(0, 0, 0, 0, 4))
+            g1 = dev.flash_attn_bwd(q, k, v, o, do, l, m, causal, variant, grads=nan(), opts=ONE)
+            g2 = dev.flash_attn_bwd(q, k, v, o, do, l, m, causal, variant, grads=nan(), opts=TWO)
         for nm, a, b in zip(("dq", "dk", "dv"), g1, g2):
             assert maxabs(back(a), ref[nm]) < TOL32, (nm, variant)
             if nm == "dq":

@@ -39,7 +39,7 @@ for ci in range(cases):
     # N % 256 == 0; key 7: paired / ranked block order of those builds)
     opts = None
     if mode == "plain" and rng.random() < 0.6:
-        opts = (int(rng.choice([0, 3, 4, 5])), int(rng.choice([0, 2, 3])), int(rng.choice([0, 2, 3])), 0, int(rng.choice([0, 0, 1, 4])),
+        opts = (int(rng.choice([0, 3, 4, 5])), int(rng.choice([0, 2, 3])), int(rng.choice([0, 2, 3])), 0, int(rng.choice([0, 0, 1, 4, 5])),
                 int(rng.integers(0, 2)), 0, int(rng.integers(0, 3)))   # (every value the product library accepts, round 3)
     desc = (ci, dtype, d, N, B, H, causal, variant, mode, opts)
     try:
