@@ -476,6 +476,9 @@ bool onepass_f32(int batch, int N, const fa::Layout& lay, int causal, int stages
         N >= 256))
     return false;
   if (tun.v[4] == 5) return true;
+  // FA_MI355X_DETERMINISTIC=1: never by default (the reference ABI has no options argument: a caller who needs a bitwise repeatable dq there)
+  static const bool deterministic = [] { const char* e = getenv("FA_MI355X_DETERMINISTIC"); return e && e[0] == '1'; }();
+  if (deterministic) return false;
   const long cus = device_cus() > 0 ? device_cus() : 256, wgs = (long)batch * ((N + 255) / 256), rounds = (wgs + cus - 1) / cus;
   return 5 * wgs >= 4 * rounds * cus;   // the launch's rounds are at least 80 % full
 }
@@ -1056,8 +1059,15 @@ std::atomic<unsigned long long> g_pin_ok{0}, g_pin_fallback{0};
 struct PinSet {
   struct Range { uintptr_t b, e; };
   std::vector<Range> want, held;
-  static bool enabled() {   // FA_MI355X_HOST_PIN=0: never pin the caller's arrays (pageable copies: slower, same results)
-    static const bool on = [] { const char* e = getenv("FA_MI355X_HOST_PIN"); return !(e && e[0] == '0'); }();
+  // Opt-in since the end of round 4 (FA_MI355X_HOST_PIN=1).  Default: the caller's arrays are copied as pageable memory, as the reference
+  // does (src/flash_attn_fw.cu:314-357): HIP's own pageable path measured the SAME time inside the C call at configs[1] / configs[2]
+  // (1.44 / 2.94 and 3.09 / 6.4 ms fw / bw) and is faster through the Python operator surface at the metric shape (13.0 vs 36.9 ms
+  // forward: registering freshly allocated result arrays faults their pages in); in-place pinning wins only the metric-shape backward
+  // (10.9 vs 15.6 ms).  And one more abort from an HSA runtime thread (main thread in a later, unrelated pageable torch copy) was seen in
+  // about fifteen runs of the GPU suite after round 3's merged-range fix: registrations of recycled heap pages by this library and the
+  // runtime's own pin cache for pageable copies can still overlap.  Not registering anything removes this library's side of that.
+  static bool enabled() {
+    static const bool on = [] { const char* e = getenv("FA_MI355X_HOST_PIN"); return e && e[0] == '1'; }();
     return on;
   }
   // EVERY host array of the call is added, whatever its size: an array that shares a page with a pinned neighbour must lie inside the

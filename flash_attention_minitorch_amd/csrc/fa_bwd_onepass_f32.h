@@ -111,9 +111,13 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   // A[i16][g4] = dS[16 qb + i16][key k0 + g4] and B[g4][i16] = K[key k0 + g4][16 db + i16]; its four result registers are rows
   // 4 g4 + j of column i16.
   const int i16 = lane & 15, g4 = lane >> 4, qb = w >> 2, db = w & 3;
+  // Bank conflicts: a K row is 68 words, so rows 4 apart sit 16 banks apart: the four keys of one MFMA are k, k + 4, k + 8, k + 12 (the B
+  // read of a lane: key k + 4 g4, 16 consecutive columns: 64 distinct banks), and the dS image stores every 16 keys with their 4 x 4
+  // index transposed (column 4 (key & 3) + ((key >> 2) & 3)), so that the A read stays four consecutive words per row (260-word rows:
+  // 64 distinct banks).  With keys k .. k + 3 per MFMA the B reads were 4-way conflicts (SQ_LDS_BANK_CONFLICT 67 M cycles per launch).
   const int ds_rd = DSB + ((16 * qb + i16) * OP32_DSROW + g4) * 4;
-  const int k_rd = KIMG + (g4 * (D + 4) + 16 * db + i16) * 4;
-  const int ds_wr = DSB + (32 * w + r) * 4;   // this lane's key column of the dS image; row acc_row(i, h)
+  const int k_rd = KIMG + (4 * g4 * (D + 4) + 16 * db + i16) * 4;
+  const int ds_wr = DSB + (32 * w + (r & 16) + 4 * (r & 3) + ((r >> 2) & 3)) * 4;   // this lane's key column of the dS image; row acc_row(i, h)
   const int dq_voff = ((16 * qb + 4 * g4) * ld + 16 * db + i16) * 4;
 
   // CAUSAL: the sweep starts at the block's own queries; in diagonal stage j = qi - 8 kb < 8 (queries 32 j .. 32 j + 31 of the block)
@@ -183,28 +187,35 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
     }
     __syncthreads();   // the stage's dS image is complete
     f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (!CAUSAL) {
+    {
+      // dQ tile: one MFMA per pinned slot, the operands of the step LA = 8 ahead requested in its shadow (left alone, hipcc requests all
+      // 128 operands of the stage at once and spills; a rolled loop without look-ahead loses 8 %).  Step st of a 32-key group: keys
+      // 16 (st >> 2) + (st & 3) + 4 g4 = image columns 4 st + g4.
+      auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+      // CAUSAL: only the 32-key groups at or below the stage's diagonal (a scalar branch per group of 8 steps)
+      const int ng = CAUSAL ? min(8, j + 1) : 8;
+      constexpr int LA = 8;
+      float ra_[LA], rb_[LA];
+      auto ld1 = [&](int st) {   // (two bases: the K image's 128-row offset does not fit the instruction's 16-bit immediate)
+        const int half = st >> 5, s5 = st & 31;
+        ra_[st % LA] = *FA_LDS(float, smem + ds_rd + half * 128 * 4 + 16 * s5);
+        rb_[st % LA] = *FA_LDS(float, smem + k_rd + (half * 128 + 16 * (s5 >> 2) + (s5 & 3)) * (D + 4) * 4);
+      };
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {   // (two halves: the K image's 128-row offset does not fit the instruction's 16-bit immediate)
-        const int kr = k_rd + half * 128 * (D + 4) * 4, dr = ds_rd + half * 128 * 4;
+      for (int st = 0; st < LA; ++st) ld1(st);
 #pragma unroll
-        for (int st = 0; st < 32; ++st) {
-          const float a = *FA_LDS(float, smem + dr + 16 * st);
-          const float b = *FA_LDS(float, smem + kr + st * 4 * (D + 4) * 4);
-          t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t4, 0, 0, 0);
+      for (int g = 0; g < 8; ++g) {
+        if (CAUSAL && g >= ng) break;
+        const bool more = !CAUSAL || g + 1 < ng;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const int st = 8 * g + s8;
+          SB();
+          t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra_[st % LA], rb_[st % LA], t4, 0, 0, 0);
+          if (st + LA < 64 && more) ld1(st + LA);
         }
       }
-    } else {
-      const int ng = min(8, j + 1);   // 32-key groups at or below the stage's diagonal
-      for (int g = 0; g < ng; ++g) {
-        const int kr = k_rd + g * 32 * (D + 4) * 4, dr = ds_rd + g * 32 * 4;
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-          const float a = *FA_LDS(float, smem + dr + 16 * st);
-          const float b = *FA_LDS(float, smem + kr + st * 4 * (D + 4) * 4);
-          t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, t4, 0, 0, 0);
-        }
-      }
+      SB();
     }
     const int soff = qi * QS * ld * 4;
     if (!RAGGED || (qi + 1) * QS <= N) {
@@ -226,17 +237,20 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   }
   if (qi < nqi) slice(ic<0>{}, qi);
 
-  if (RAGGED && kw0 + r >= N) return;
-  float* dkrow = dk + base + (size_t)(kw0 + r) * ld;
-  float* dvrow = dv + base + (size_t)(kw0 + r) * ld;
+  // (the lane's row and half re-derived from v_mbcnt: kept from kernel entry they are two registers across the sweep, spilled)
+  const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int er = ln & 31, eh = ln >> 5;
+  if (RAGGED && kw0 + er >= N) return;
+  float* dkrow = dk + base + (size_t)(kw0 + er) * ld;
+  float* dvrow = dv + base + (size_t)(kw0 + er) * ld;
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 a = {acc_dk[dt][4 * g] * tau, acc_dk[dt][4 * g + 1] * tau, acc_dk[dt][4 * g + 2] * tau, acc_dk[dt][4 * g + 3] * tau};
       f32x4 b = {acc_dv[dt][4 * g], acc_dv[dt][4 * g + 1], acc_dv[dt][4 * g + 2], acc_dv[dt][4 * g + 3]};
-      *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * h) = a;
-      *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * h) = b;
+      *reinterpret_cast<f32x4*>(dkrow + 32 * dt + 8 * g + 4 * eh) = a;
+      *reinterpret_cast<f32x4*>(dvrow + 32 * dt + 8 * g + 4 * eh) = b;
     }
 }
 

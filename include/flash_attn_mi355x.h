@@ -76,9 +76,11 @@ void fa_mi355x_launch_bw_host(int variant, float* q, float* k, float* v, float* 
                               float* q_grad, float* k_grad, float* v_grad, float* l, float* m,
                               int batch, int N, int d, bool causal_mask, void* stream);
 
-/* The host launchers pin the caller's arrays in place for the duration of a call (page-aligned, merged ranges of at least 4 MiB;
- * hipHostRegister).  Cumulative, process-wide: how many such ranges were registered, and how many could not be (already registered by
- * the caller, or not lockable) and were copied pageable instead -- same results, slower.  Either pointer may be NULL. */
+/* The host launchers copy the caller's arrays as pageable memory (the reference's cudaMemcpy calls do the same).  With FA_MI355X_HOST_PIN=1
+ * in the environment they pin them in place for the duration of a call instead (page-aligned, merged ranges of at least 4 MiB;
+ * hipHostRegister): faster only for backward calls of hundreds of MiB, see fa_api.hip (PinSet).  Cumulative, process-wide: how many such
+ * ranges were registered, and how many could not be (already registered by the caller, or not lockable) and were copied pageable
+ * instead -- same results.  Both stay 0 without the opt-in.  Either pointer may be NULL. */
 void fa_mi355x_host_pin_stats(unsigned long long* pinned_ranges, unsigned long long* pageable_ranges);
 
 /* Forward on device pointers.  q,k,v: dtype elements [batch][N][d]; out: float [batch][N][d];
@@ -138,7 +140,8 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *            the reference does at :228 -- 131 vs 98.5 TFLOP/s at BASELINE configs[2] because the exact-fp32 MFMA bounds it, not the
  *            atomics (launches that leave CUs idle stay on the two kernels' finer workgroups: 128 workgroups 0.64 vs 0.49 ms).  dq then
  *            differs from run to run in the last bits (order of the N/256 adds per element; dk, dv are bitwise stable); 4 restores
- *            the bitwise repeatable two-kernel path;
+ *            the bitwise repeatable two-kernel path (FA_MI355X_DETERMINISTIC=1 in the environment does the same for every call
+ *            that does not ask for 5: the reference's launch_flash_attn_bw has no options argument);
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads
  *            per workgroup when the launch still covers every CU), and so does the non-causal d = 64 dQ kernel (default: query block
  *            qb of several consecutive heads, same condition); bitwise the same results
