@@ -566,23 +566,22 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     constexpr int SUBN = decltype(subn_c)::value, SUBP = decltype(subp_c)::value, SUB2 = decltype(sub2_c)::value;
     constexpr int SUBC = decltype(subc_c)::value;
     float rs = 0.f, cm = c;
-    f32x2 rs2 = {0.f, 0.f};   // the row sum as two partial sums: one v_pk_add_f32 per PAIR of scores (8 instead of 16 adds per sub-tile; same time, A/B in profiles/README.md)
     if constexpr (MASK) {
       asm volatile("" : "+v"(cm));   // keeps hipcc from hoisting the two variants' common fma out of the branch
       if constexpr (HC) mask_scores(cs, kcur);
     }
     auto fe = [&](int i) {
-      cs[i] = PRE ? __builtin_amdgcn_exp2f(cs[i]) : __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nmc));
+      const float pv = PRE ? __builtin_amdgcn_exp2f(cs[i]) : __builtin_amdgcn_exp2f(__builtin_fmaf(cs[i], cm, nmc));
+      cs[i] = pv;
+      rs += pv;
     };
-    // softmax work of slot g: its EPS scores (and the row-sum add of every pair they complete), then the bf16 pack of the pairs
-    // completed by the slot before (the last slot also packs its own)
+    // softmax work of slot g: its EPS scores, then the bf16 pack of the pairs completed by the slot before (the last
+    // slot also packs its own).  (The row sum on v_pk_add_f32 -- 8 adds per sub-tile instead of 16 -- measured the same time, guarded
+    // and unguarded, in same-process A/Bs: 0.2469 vs 0.2471 and 0.2383 vs 0.2381 ms; profiles/README.md, round 4.  Not kept.)
     auto valu = [&](int g) {
       if constexpr (HC) {
 #pragma unroll
         for (int e = 0; e < EPS; ++e) fe(g * EPS + e);
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-          if ((2 * p + 1) / EPS == g) rs2 += f32x2{cs[2 * p], cs[2 * p + 1]};
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           const int done_at = (2 * p + 1) / EPS;   // slot that finishes pair p
@@ -621,7 +620,6 @@ fwd_slot_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
       }
       SB();
     }
-    if constexpr (HC) rs = rs2[0] + rs2[1];
     if constexpr (HC && PRE) l_run += rs;   // no reference to move: the range check sits at the end of the block
     if constexpr (HC && !PRE) {
       float alpha = 1.0f;

@@ -2,7 +2,7 @@
 """A/B of two builds of the core library in ONE process on one device (box-to-box spread is larger than most kernel changes):
 library A = the in-tree product build, library B = another build of csrc/fa_api.hip (e.g. with a -D switch), both loaded with ctypes
 and timed alternately on the same tensors through fa_mi355x_fwd_ex / fa_mi355x_bwd_stages_ex-free entry points.
-usage: python tools/ab_two_libs.py path/to/libB.so [fwd|bwd] [causal]"""
+usage: python tools/ab_two_libs.py path/to/libB.so [fwd|bwd|fwdg|bwdg] [causal]   (fwdg / bwdg: the guarded default calls)"""
 import ctypes
 import os
 import sys
@@ -17,7 +17,7 @@ from flash_attention_minitorch_amd import _lib, device_ops  # noqa: E402
 def load(path):
     lib = ctypes.CDLL(path)
     src = _lib.core()
-    for name in ("fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex"):
+    for name in ("fa_mi355x_fwd_ex", "fa_mi355x_bwd_ex", "fa_mi355x_fwd_guarded", "fa_mi355x_bwd_guarded"):
         f, g = getattr(lib, name), getattr(src, name)
         f.argtypes, f.restype = g.argtypes, g.restype
     return lib
@@ -48,8 +48,22 @@ def main():
                                   causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_BF16, device_ops.STAGE_ALL, arr, cnt, st)
         assert rc == 0, rc
 
+    guard = device_ops.new_guard(q)
+    arr0, cnt0 = _lib.opts_array(None)
+
+    def fwdg(lib):   # the default call of device_ops / bench.py: the forward fills the scale guard inside its own launch
+        rc = lib.fa_mi355x_fwd_guarded(p(q), p(k), p(v), p(o), p(L), None, B * H, 1, N, d, 0, 0.0, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_BF16,
+                                       arr0, cnt0, p(guard), 1, st)
+        assert rc == 0, rc
+
+    def bwdg(lib):
+        rc = lib.fa_mi355x_bwd_guarded(p(q), p(k), p(v), p(o), p(do), p(grads[0]), p(grads[1]), p(grads[2]), p(L), None, p(ws), B * H, 1, N, d, 0,
+                                       0.0, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_BF16, device_ops.STAGE_ALL, arr0, cnt0, p(guard), st)
+        assert rc == 0, rc
+
     fwd(libs["A"])
-    fn = fwd if what == "fwd" else bwd
+    fwdg(libs["A"])
+    fn = {"fwd": fwd, "bwd": bwd, "fwdg": fwdg, "bwdg": bwdg}[what]
     res = {"A": [], "B": []}
     for rnd in range(6):
         for name in ("A", "B"):
