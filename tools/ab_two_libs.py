@@ -2,7 +2,7 @@
 """A/B of two builds of the core library in ONE process on one device (box-to-box spread is larger than most kernel changes):
 library A = the in-tree product build, library B = another build of csrc/fa_api.hip (e.g. with a -D switch), both loaded with ctypes
 and timed alternately on the same tensors through fa_mi355x_fwd_ex / fa_mi355x_bwd_stages_ex-free entry points.
-usage: python tools/ab_two_libs.py path/to/libB.so [fwd|bwd|fwdg|bwdg] [causal]   (fwdg / bwdg: the guarded default calls)"""
+usage: python tools/ab_two_libs.py path/to/libB.so [fwd|bwd|fwdg|bwdg|fwd32|bwd32] [causal]   (fwdg / bwdg: the guarded default calls; *32: fp32 at configs[2])"""
 import ctypes
 import os
 import sys
@@ -63,7 +63,26 @@ def main():
 
     fwd(libs["A"])
     fwdg(libs["A"])
-    fn = {"fwd": fwd, "bwd": bwd, "fwdg": fwdg, "bwdg": bwdg}[what]
+    # fp32 (the reference's dtype) at BASELINE configs[2]: B=8 H=8 N=2048 d=64, FA-1 side outputs
+    N32 = 2048
+    q32, k32, v32, do32 = ((torch.rand((B * H, N32, d), device="cuda", generator=gen) - 0.5) * 2 for _ in range(4))
+    o32 = torch.empty((B * H, N32, d), dtype=torch.float32, device="cuda")
+    l32, m32 = (torch.empty((B * H, N32), dtype=torch.float32, device="cuda") for _ in range(2))
+    g32 = [torch.empty_like(o32) for _ in range(3)]
+    ws32 = device_ops.bwd_workspace(q32)
+
+    def fwd32(lib):
+        rc = lib.fa_mi355x_fwd_ex(p(q32), p(k32), p(v32), p(o32), p(l32), p(m32), B * H, N32, d, causal, _lib.FA_VARIANT_FA1, _lib.FA_DTYPE_F32,
+                                  arr0, cnt0, st)
+        assert rc == 0, rc
+
+    def bwd32(lib):
+        rc = lib.fa_mi355x_bwd_ex(p(q32), p(k32), p(v32), p(o32), p(do32), p(g32[0]), p(g32[1]), p(g32[2]), p(l32), p(m32), p(ws32), B * H, N32, d,
+                                  causal, _lib.FA_VARIANT_FA1, _lib.FA_DTYPE_F32, device_ops.STAGE_ALL, arr0, cnt0, st)
+        assert rc == 0, rc
+
+    fwd32(libs["A"])
+    fn = {"fwd": fwd, "bwd": bwd, "fwdg": fwdg, "bwdg": bwdg, "fwd32": fwd32, "bwd32": bwd32}[what]
     res = {"A": [], "B": []}
     for rnd in range(6):
         for name in ("A", "B"):
