@@ -195,8 +195,14 @@ def run_extras(torch, device_ops, q, k, v, do, causal, B, H):
         tf, tb = vg.time_ms(fw, iters, warm), vg.time_ms(bw, iters, warm)
         cf = 0.5 if caus else 1.0
         fl_fw, fl_bw = 4.0 * B * H * N_ * N_ * d_ * cf, 10.0 * B * H * N_ * N_ * d_ * cf
+        tfl = [(fl_fw + fl_bw) / (tf + tb) / 1e9, fl_fw / tf / 1e9, fl_bw / tb / 1e9]
+        peak = PEAK_F32_TFLOPS if tdt == torch.float32 else PEAK_BF16_TFLOPS   # dense MFMA peak of the arithmetic type
+        dt_ = _lib.FA_DTYPE_F32 if tdt == torch.float32 else _lib.FA_DTYPE_BF16
         return {"ms_total_fw_bw": [round(tf + tb, 4), round(tf, 4), round(tb, 4)],
-                "tflops_total_fw_bw": [round((fl_fw + fl_bw) / (tf + tb) / 1e9, 1), round(fl_fw / tf / 1e9, 1), round(fl_bw / tb / 1e9, 1)]}
+                "tflops_total_fw_bw": [round(x, 1) for x in tfl],
+                "frac_of_mfma_peak": [round(x / peak, 4) for x in tfl], "mfma_peak_tflops": peak,
+                # what the backward call launches (fa_mi355x_plan): fp32 d = 64 launches that fill the chip take the one-pass kernel
+                "bw_kernels": _lib.plan(B * H, N_, d_, caus, variant, dt_, device_ops.STAGE_ALL, None)}
 
     f32, bf = torch.float32, torch.bfloat16
     FA1, FA2 = _lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2
@@ -471,7 +477,7 @@ def main():
         # algorithmic split of the backward's 10*B*H*N^2*d: dK/dV kernel owns S, dP, dV, dK (4 GEMMs), dQ kernel owns
         # dQ (1 GEMM); the dQ kernel's recomputation of S and dP is not algorithmic work and is not counted.
         alg = {"scale_guard_kernel": 0.0, K_FWD: flops_fw, "bwd_prep_kernel": 0.0, K_DKDV: 8.0 * BH * N * N * d * cf,
-               K_DQ: 2.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw}
+               K_DQ: 2.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw, "bwd_onepass_f32_kernel": flops_bw}
         for i, (name, _) in enumerate(STAGES):   # the dominant kernel: from the timed region; the others: the pass before it
             evs = events if i == dom_stage else pre_events
             ms = sum(ev[i].elapsed_time(ev[i + 1]) for ev in evs) / args.steps
@@ -480,7 +486,8 @@ def main():
         dur_ms, fl = kernels[dom]
         # every kernel against the same roofline, counted (algorithmic) and executed work: the dQ kernel recomputes S^T and dP^T
         # (6 GEMM units executed for the 2 it is credited with); stage times include the launches that return at the guard check
-        executed = {K_FWD: flops_fw, K_DKDV: 8.0 * BH * N * N * d * cf, K_DQ: 6.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw}
+        executed = {K_FWD: flops_fw, K_DKDV: 8.0 * BH * N * N * d * cf, K_DQ: 6.0 * BH * N * N * d * cf, "bwd_fused_kernel": flops_bw,
+                    "bwd_onepass_f32_kernel": flops_bw}
         pk = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         kernel_rooflines = {n: {"ms": round(ms_, 4), "algorithmic_tflops": round(fl_ / (ms_ * 1e-3) / 1e12, 1),
                                 "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / pk, 4),
