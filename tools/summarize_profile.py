@@ -8,7 +8,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
-KNAMES = ("scale_guard_kernel", "fwd_slot_kernel", "fwd_kernel", "bwd_prep_kernel", "bwd_fused_kernel", "bwd_chain_kernel", "bwd_dkdv_slot_kernel", "bwd_dkdv_kernel",
+KNAMES = ("scale_guard_kernel", "fwd_slot_kernel", "fwd_kernel", "bwd_prep_kernel", "bwd_onepass_f32_kernel", "bwd_fused_kernel", "bwd_chain_kernel", "bwd_dkdv_slot_kernel", "bwd_dkdv_kernel",
           "bwd_dq_slot_kernel", "bwd_dq_kernel")
 
 def short(name):   # mangled fa:: kernel name -> the name bench.py reports
