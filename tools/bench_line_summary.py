@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Prints the kernel times, the sustained MFMA figure and the value / median / blocks of the last bench line in gpurun_out/bench.log."""
 import json,sys
 l=[x for x in open("gpurun_out/bench.log") if x.startswith("{")][-1]
 d=json.loads(l)

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Times the fp32 d = 64 backward (two kernels / one-pass forced / the library's choice) at launches below and at the size of the chip:
+the measurement behind the one-pass kernel's dispatch rule (profiles/r04_onepass_f32_launch_sizes.txt).  usage: python tools/sweep_onepass_f32.py"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import check_onepass_f32 as c
