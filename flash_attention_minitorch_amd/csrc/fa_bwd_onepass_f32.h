@@ -17,8 +17,11 @@
 // read per lane and MFMA -- and adds tau * tile to dq: four no-return atomics per wave and stage, each register four whole 64-byte row
 // segments.  CAUSAL (the reference's causal kernels skip and mask the same way: src/flash_attn_causal_bw.cu, the j > i tiles): key
 // block kb starts its sweep at its own queries; on the 8 diagonal stages the waves whose keys are all masked sit out, the wave on the
-// diagonal masks above it, and dQ sums the live keys only; blocks are dispatched longest sweep first (map_block_ranked).  Measured
-// (profiles/r04_onepass_f32.txt): 131 vs 98 TFLOP/s non-causal and 117 vs 86 causal at B=8 H=8 N=2048 against the two-kernel path.
+// diagonal masks above it, and dQ sums the live keys only; blocks are dispatched longest sweep first (map_block_ranked).  RAGGED: N not
+// a multiple of 256 (its own builds).  The geometry keeps whole CUs busy only when the launch has about a workgroup per CU: the launcher
+// (fa_api.hip: onepass_f32) sends smaller launches to the two kernels.  Measured (profiles/r04_onepass_f32.txt, r04_f32_pmc.json):
+// 135 vs 98 TFLOP/s non-causal and 119 vs 87 causal at B=8 H=8 N=2048 against the two-kernel path, 138 at N = 4096 (88.7 % MFMA-busy
+// at 2.39 GHz: fp32 MFMAs stay under the power limit; HBM traffic = the algorithmic bytes + the atomic adds, 0.22 TB/s).
 // dq must be zero on entry (the launcher fills it; the reference's caller does the same, minitorch/cuda_kernel_ops.py:609-611).
 #pragma once
 #include "fa_common.h"
