@@ -465,22 +465,30 @@ int dq_slot_launch(const void* q, const void* k, const void* v, const void* dout
 // diagnostic build; option 4 = 1 keeps the separate preprocess kernel (A/B), 2 is the one-pass backward.
 // fp32, d = 64, N >= 256, no key mask / dropout, dQ and dK/dV asked for together: the one-pass backward
 // (fa_bwd_onepass_f32.h: five products instead of the two-kernel path's seven, dQ by fp32 atomics) when its launch fills the chip:
-// one 8-wave workgroup per CU and 256-key block, so batch * ceil(N / 256) workgroups run in ceil(that / CUs) rounds; it takes the
-// call when the last round is full enough that 7/5 of the work on finer workgroups would be slower (measured, profiles/
-// r04_onepass_f32.txt: 128 workgroups 0.64 vs 0.49 ms, 256 workgroups 0.18 vs 0.24).  Option 4: 4 = two kernels always (dq bitwise
-// repeatable from run to run), 5 = one pass whatever the launch size.
+// one 8-wave workgroup per CU and 256-key block, so batch * ceil(N / 256) workgroups run in ceil(that / CUs) rounds; below one
+// workgroup per CU the query sweep of every key block is cut into 2, 4 or 8 parts (one workgroup each; dK and dV are then added with
+// atomics as well).  It takes the call when the rounds are at least 80 % full (measured, profiles/r04_onepass_f32_launch_sizes.txt: B = 1,
+// H = 8, N = 1024 -- the reference's own test shape -- 0.085 vs 0.240 ms in 8 parts; 128 unsplit workgroups would be 0.64 vs 0.49).
+// Returns the number of parts, 0 = two kernels.  Option 4: 4 = two kernels always (dq bitwise repeatable from run to run), 5 = one
+// pass whatever the launch size.
 template <typename T, int D>
-bool onepass_f32(int batch, int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {
+int onepass_f32(int batch, int N, const fa::Layout& lay, int causal, int stages, const Tun& tun) {   // 0: two kernels; else the split
   const int both = FA_BWD_STAGE_DKDV | FA_BWD_STAGE_DQ;
   if (!(sizeof(T) == 4 && D == 64 && (stages & both) == both && (tun.v[4] == 0 || tun.v[4] == 5) && !lay.kmask && !lay.drop_thr &&
         N >= 256))
-    return false;
-  if (tun.v[4] == 5) return true;
+    return 0;
   // FA_MI355X_DETERMINISTIC=1: never by default (the reference ABI has no options argument: a caller who needs a bitwise repeatable dq there)
   static const bool deterministic = [] { const char* e = getenv("FA_MI355X_DETERMINISTIC"); return e && e[0] == '1'; }();
-  if (deterministic) return false;
-  const long cus = device_cus() > 0 ? device_cus() : 256, wgs = (long)batch * ((N + 255) / 256), rounds = (wgs + cus - 1) / cus;
-  return 5 * wgs >= 4 * rounds * cus;   // the launch's rounds are at least 80 % full
+  if (deterministic && tun.v[4] != 5) return 0;
+  // Launches below one workgroup per CU: the query sweep of every key block is cut into 2, 4 or 8 parts (one workgroup each, dK / dV
+  // summed by atomics as well) while a part keeps at least 4 stages of 32 queries
+  const long cus = device_cus() > 0 ? device_cus() : 256, wgs1 = (long)batch * ((N + 255) / 256), nqi = (N + 31) / 32;
+  for (int split = 1; split <= 8; split *= 2) {
+    if (split > 1 && nqi / split < 4) break;
+    const long wgs = wgs1 * split, rounds = (wgs + cus - 1) / cus;
+    if (5 * wgs >= 4 * rounds * cus) return split;   // the launch's rounds are at least 80 % full
+  }
+  return tun.v[4] == 5 ? 1 : 0;
 }
 
 template <typename T, int D>
@@ -582,15 +590,21 @@ int bwd_launch(const void* q, const void* k, const void* v, const float* out, co
     if (rc) return rc;
   }
   if constexpr (sizeof(T) == 4 && D == 64) {
-    if (onepass_f32<T, D>(batch, N, lay, causal, stages, tun)) {
+    if (const int nsplit = onepass_f32<T, D>(batch, N, lay, causal, stages, tun)) {
       // the workgroups ADD into dq (the reference's caller zeroes q_grad for its atomicAdd as well: minitorch/cuda_kernel_ops.py:609-611);
       // [B][N][H][d] or [BH][N][d]: the tensor is one contiguous range either way
-      if (!t_probe && !t_plan) FA_HIP_TRY(hipMemsetAsync(dq, 0, (size_t)rows * D * sizeof(float), st));
+      if (!t_probe && !t_plan) {
+        FA_HIP_TRY(hipMemsetAsync(dq, 0, (size_t)rows * D * sizeof(float), st));
+        if (nsplit > 1) {   // the parts of a key block's sweep ADD their dK, dV
+          FA_HIP_TRY(hipMemsetAsync(dk, 0, (size_t)rows * D * sizeof(float), st));
+          FA_HIP_TRY(hipMemsetAsync(dv, 0, (size_t)rows * D * sizeof(float), st));
+        }
+      }
       const int nkb = (N + 255) / 256;
       if (causal) lay.rank_chunk = rank_chunk(1, nkb);   // key block 0 (the longest sweep) of a chunk of heads first
 #define FA_ONEPASS(C, R)                                                                                                             \
-  FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, C, R>), dim3((unsigned)(batch * nkb)), dim3(512), 0, st, (const float*)q, (const float*)k, \
-            (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau)
+  FA_LAUNCH((fa::bwd_onepass_f32_kernel<D, C, R>), dim3((unsigned)(batch * nkb * nsplit)), dim3(512), 0, st, (const float*)q, (const float*)k, \
+            (const float*)v, (const float*)dout, nlc, delta, dq, dk, dv, N, nkb, batch, lay, tau, nsplit)
       if (N % 256 == 0) {
         if (causal) FA_ONEPASS(true, false); else FA_ONEPASS(false, false);
       } else {

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(512, 2)
 bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                        const float* __restrict__ dout, const float* __restrict__ nlc, const float* __restrict__ ndelta,
                        float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, int N, int nkb, int BH, Layout lay,
-                       float tau) {
+                       float tau, int nsplit) {
   if (guard_skip(lay)) return;
   static_assert(D == 64, "laid out for d = 64");
   using A = Atom<float>;
@@ -52,9 +52,12 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // nsplit > 1 (launches that would leave CUs idle): the query sweep of a key block is cut into nsplit consecutive parts, one workgroup
+  // each; dK and dV are then sums over the parts as well: atomic adds into zero-filled dk, dv (two parts: still bitwise repeatable)
+  const int sp = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit)), idb = (int)(blockIdx.x / (unsigned)nsplit);
   int bh, kb;
-  if (CAUSAL) map_block_ranked(blockIdx.x, BH, nkb, max(lay.rank_chunk, 1), bh, kb);   // key block 0 sweeps the most stages: first
-  else map_block(blockIdx.x, BH, nkb, bh, kb);
+  if (CAUSAL) map_block_ranked(idb, BH, nkb, max(lay.rank_chunk, 1), bh, kb);   // key block 0 sweeps the most stages: first
+  else map_block(idb, BH, nkb, bh, kb);
   const size_t base = head_base(lay, bh);
   const int ld = lay.ld;
   const uint32_t mat_bytes = ((uint32_t)(N - 1) * ld + D) * 4u;
@@ -127,9 +130,12 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   // waves w > j see masked keys only and sit the stage out, wave j masks above its diagonal, and dQ sums the 32 (j + 1) live keys
   // RAGGED (N not a multiple of 256; its own build: the checks cost the aligned one 4-6 %): rows past N are staged as zeros (Q, dO, K; V by its resource's range check); the last key block clears P at its keys >= N,
   // the last stage skips the adds of its rows >= N, the epilogue the stores of its keys >= N.
-  const int nqi = (N + QS - 1) / QS, qi0 = CAUSAL ? kb * (OP32_BK / QS) : 0;
+  const int qi0 = CAUSAL ? kb * (OP32_BK / QS) : 0;   // (the diagonal stages are counted from here whatever part this workgroup sweeps)
+  const int nq_all = (N + QS - 1) / QS, per = (nq_all - qi0 + nsplit - 1) / nsplit;
+  const int q_begin = qi0 + sp * per, nqi = min(nq_all, q_begin + per);
+  if (q_begin >= nqi) return;   // (more parts than stages: nothing to add; before any barrier)
   const bool ragged_keys = RAGGED && kw0 + 32 > N;   // (wave-uniform)
-  stage_load(qi0);
+  stage_load(q_begin);
   stage_store(smem);
   __syncthreads();
 
@@ -233,7 +239,7 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
     if (more) stage_store(smem + (PAR ^ 1) * STG);
     __syncthreads();   // the next stage is published; every wave is done with this stage's dS image
   };
-  int qi = qi0;
+  int qi = q_begin;
   for (; qi + 1 < nqi; qi += 2) {
     slice(ic<0>{}, qi);
     slice(ic<1>{}, qi + 1);
@@ -243,6 +249,30 @@ bwd_onepass_f32_kernel(const float* __restrict__ q, const float* __restrict__ k,
   // (the lane's row and half re-derived from v_mbcnt: kept from kernel entry they are two registers across the sweep, spilled)
   const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int er = ln & 31, eh = ln >> 5;
+  if (nsplit > 1) {
+    // dK, dV of this part are ADDED (dk, dv zero-filled by the launcher).  The accumulators hold a key per lane (rows 256 B apart): every
+    // wave transposes its two 32 x 64 tiles through LDS (all images are free after the sweep's last barrier; 65-word rows: conflict-free
+    // both ways) so that one atomic instruction adds one whole 256-byte row (lane = column) instead of 64 scattered words.
+    lds_char* tw = smem + w * (2 * 32 * 65 * 4);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = (er * 65 + 32 * dt + acc_row(i, eh)) * 4;
+        *FA_LDS(float, tw + o) = acc_dk[dt][i] * tau;
+        *FA_LDS(float, tw + 32 * 65 * 4 + o) = acc_dv[dt][i];
+      }
+    const rsrc_t dkrs = make_rsrc(dk + base, mat_bytes), dvrs = make_rsrc(dv + base, mat_bytes);
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      if (RAGGED && kw0 + kk >= N) break;
+      const float x = *FA_LDS(float, tw + (kk * 65 + ln) * 4);
+      const float y = *FA_LDS(float, tw + 32 * 65 * 4 + (kk * 65 + ln) * 4);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(x, dkrs, ln * 4, (kw0 + kk) * ld * 4, 0);
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(y, dvrs, ln * 4, (kw0 + kk) * ld * 4, 0);
+    }
+    return;
+  }
   if (RAGGED && kw0 + er >= N) return;
   float* dkrow = dk + base + (size_t)(kw0 + er) * ld;
   float* dvrow = dv + base + (size_t)(kw0 + er) * ld;

@@ -135,11 +135,13 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *            BEFORE the dK/dV launch; same results up to summation order of delta);
  *            4 / 5 = fp32, d = 64: two kernels always / the ONE-PASS backward whatever the launch size.  By default an fp32, d = 64
  *            backward with N >= 256 and no key mask / dropout, asked for dQ and dK/dV together, runs bwd_onepass_f32_kernel when its
- *            launch -- batch * ceil(N / 256) workgroups, one per CU -- runs in rounds that are at least 80 % full: the five products of
+ *            launch -- batch * ceil(N / 256) workgroups, one per CU; below that the query sweep of every key block is cut into 2, 4
+ *            or 8 workgroups, which then add their dK, dV as well -- runs in rounds that are at least 80 % full: the five products of
  *            src/flash_attn2_bw.cu:94-247 in one key-stationary pass, dQ added to the (library zero-filled) q_grad with fp32 atomics as
  *            the reference does at :228 -- 131 vs 98.5 TFLOP/s at BASELINE configs[2] because the exact-fp32 MFMA bounds it, not the
- *            atomics (launches that leave CUs idle stay on the two kernels' finer workgroups: 128 workgroups 0.64 vs 0.49 ms).  dq then
- *            differs from run to run in the last bits (order of the N/256 adds per element; dk, dv are bitwise stable); 4 restores
+ *            atomics (B = 1, H = 8, N = 1024: 0.085 vs 0.240 ms in 8 parts; launches that stay under 80 % keep the two kernels).  dq then
+ *            differs from run to run in the last bits (order of the N/256 adds per element; dk, dv are bitwise stable unless the sweeps
+ *            are cut into 4 or 8 parts); 4 restores
  *            the bitwise repeatable two-kernel path (FA_MI355X_DETERMINISTIC=1 in the environment does the same for every call
  *            that does not ask for 5: the reference's launch_flash_attn_bw has no options argument);
  *   opts[5]  1 = the non-causal d = 64 dK/dV kernel takes one head per workgroup (default: key block kb of several consecutive heads

@@ -66,5 +66,6 @@ def test_plan_of_option_and_feature_paths():
     assert _lib.plan(64, 2048, 64, True, _lib.FA_VARIANT_FA1, f32, 7, (0, 0, 0, 0, 4)) == ["bwd_prep_kernel", "bwd_dkdv_kernel", "bwd_dq_kernel"]
     assert _lib.plan(64, 200, 64, True, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
     assert _lib.plan(64, 2048, 32, False, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]
-    assert _lib.plan(16, 2048, 64, False, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]   # 128 workgroups: half the chip
-    assert _lib.plan(16, 2048, 64, False, _lib.FA_VARIANT_FA1, f32, 7, (0, 0, 0, 0, 5)) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]
+    assert _lib.plan(2, 2048, 64, False, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_dq_kernel", "bwd_dkdv_kernel"]   # 16 key blocks: even cut 8 ways, half the chip
+    assert _lib.plan(2, 2048, 64, False, _lib.FA_VARIANT_FA1, f32, 7, (0, 0, 0, 0, 5)) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]
+    assert _lib.plan(16, 2048, 64, False, _lib.FA_VARIANT_FA1, f32, 7) == ["bwd_prep_kernel", "bwd_onepass_f32_kernel"]   # 128 blocks x 2 parts
