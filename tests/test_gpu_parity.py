@@ -249,7 +249,7 @@ def test_fp32_one_pass_backward(dev, N, bnhd, causal):
         for nm, a, b in zip(("dq", "dk", "dv"), g1, g2):
             assert maxabs(back(a), ref[nm]) < TOL32, (nm, variant)
             if nm == "dq" or N > 1024:   # (N = 1280 with 6 heads: the forced one-pass call cuts every sweep into 8 parts, dk / dv are sums too)
-                assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+                assert float((a - b).abs().max()) < 5e-6 * max(1.0, float(b.abs().max()))
             else:
                 assert torch.equal(a, b), nm
 
@@ -275,7 +275,8 @@ def test_fp32_one_pass_backward_split_sweeps(dev, BH, N, causal):
     ref = oracle_heads(*arrs, causal, heads)
     for nm, a, b in zip(("dq", "dk", "dv"), g1, g2):
         assert bool(torch.isfinite(a).all()), nm
-        assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max())), nm
+        # (two summation orders of a few thousand fp32 terms: the oracle bound below is the parity check)
+        assert float((a - b).abs().max()) < 5e-6 * max(1.0, float(b.abs().max())), nm
         assert maxabs(to_np(a)[heads], ref[nm]) < TOL32, nm
 
 
