@@ -485,7 +485,8 @@ int onepass_f32(int batch, int N, const fa::Layout& lay, int causal, int stages,
   const long cus = device_cus() > 0 ? device_cus() : 256, wgs1 = (long)batch * ((N + 255) / 256), nqi = (N + 31) / 32;
   // (causal: key block 0 sweeps N / 256 times the stages of the last one, so one round is bound by its longest workgroup -- 0.65 ms
   // against 0.36 of balanced work at B = 4, H = 8, N = 2048: first look for a cut that gives the longest-first dispatch two rounds)
-  for (int pass = causal ? 0 : 1; pass < 2; ++pass)
+  // (from four key blocks per head on: at N = 256 / 512 the cut costs more than the imbalance, 0.146 vs 0.087 and 0.181 vs 0.164 ms)
+  for (int pass = (causal && N >= 1024) ? 0 : 1; pass < 2; ++pass)
     for (int split = 1; split <= 8; split *= 2) {
       if (split > 1 && nqi / split < 4) break;
       const long wgs = wgs1 * split, rounds = (wgs + cus - 1) / cus;
