@@ -221,3 +221,23 @@ def test_native_backtrace_hook_fires_on_abort(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from gpu_util import check_abort_hook
     check_abort_hook(tmp_path)
+
+
+def test_deterministic_switch_keeps_the_two_kernel_fp32_backward(built):
+    """FA_MI355X_DETERMINISTIC=1 (read once per process: a child): the fp32 d = 64 backward stays on two kernels (dq bitwise repeatable)
+    for callers of the reference ABI, which has no options argument; option 4 = 5 still forces the one-pass kernel.  fa_mi355x_plan
+    runs the library's own dispatch without a GPU."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from flash_attention_minitorch_amd import _lib\n"
+            "f32 = _lib.FA_DTYPE_F32\n"
+            "print(_lib.plan(64, 2048, 64, False, 2, f32, 7, None), _lib.plan(64, 2048, 64, False, 2, f32, 7, (0, 0, 0, 0, 5)))\n") % root
+    out = {}
+    for val in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, FA_MI355X_DETERMINISTIC=val))
+        assert r.returncode == 0, r.stderr[-1000:]
+        out[val] = r.stdout.strip()
+    assert out["0"] == "['bwd_prep_kernel', 'bwd_onepass_f32_kernel'] ['bwd_prep_kernel', 'bwd_onepass_f32_kernel']", out["0"]
+    assert out["1"] == "['bwd_dq_kernel', 'bwd_dkdv_kernel'] ['bwd_prep_kernel', 'bwd_onepass_f32_kernel']", out["1"]
