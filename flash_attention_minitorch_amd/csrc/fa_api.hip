@@ -77,6 +77,10 @@ void plan_add(const char* expr) {   // "(fa::fwd_slot_kernel<T, 64, false>)" -> 
     FA_LAUNCH_FOLD(kern, grid, block, shmem, st, __VA_ARGS__);              \
   } while (0)
 
+// fwd_kernel workgroups per CU up to which the fp32 split-key forward takes the launch (measured, profiles/r04_fwd_splitk_f32.txt: 64 / 128
+// workgroups 0.076 -> 0.027 / 0.044 ms, 256 level, 512 slower; causal: 256 workgroups 0.160 -> 0.111, 512 slower)
+constexpr double FWD_SPLITK_MAX_WGS_PER_CU = 0.5, FWD_SPLITK_MAX_WGS_PER_CU_CAUSAL = 1.0;
+
 inline bool d_supported(int d) { return d == 32 || d == 64 || d == 128; }
 inline int d_padded(int d) { return d <= 32 ? 32 : (d <= 64 ? 64 : 128); }
 
@@ -107,7 +111,7 @@ int parse_opts(const int* opts, int nopts, Tun& t) {
 #ifndef FA_DIAG
   // (round 3 library diet: the values that lost their A/B and had no test -- opts[0] = 1 / 2, opts[1] = 6, opts[2] = 1 / 4, opts[3] = 1,
   // opts[4] = 2 (the one-pass backward), opts[6] = 1 -- exist in the diagnostic build only, together with their kernels)
-  static const int allowed[NTUN][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, 4, 5, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1},
+  static const int allowed[NTUN][7] = {{0, 3, 4, 5, -1}, {0, 2, 3, 4, -1}, {0, 2, 3, -1}, {0, -1}, {0, 1, 4, 5, -1}, {0, 1, -1}, {0, -1}, {0, 1, 2, -1},
                                        {0, 1, 2, 3, -1}, {0, 1, -1}};
   for (int i = 0; i < NTUN; ++i) {
     bool ok = false;
@@ -241,6 +245,20 @@ int fwd_launch_cfg(const void* q, const void* k, const void* v, float* out, floa
 template <typename T, int D>
 int fwd_launch(const void* q, const void* k, const void* v, float* out, float* l, float* m, int batch, int N,
                fa::Layout lay, int causal, int variant, float tau, hipStream_t st, const Tun& tun) {
+  if constexpr (sizeof(T) == 4 && D == 64) {
+    // fp32, d = 64, launches that leave most of the chip idle under fwd_kernel's geometry (a wave = 32 queries x all keys, 128-query
+    // workgroups, two per CU): the split-key forward (fa_fwd_splitk_f32.h: a workgroup = one 32-query block, its four waves a quarter
+    // of the keys each).  Option 1: 4 = always, 2 = never.
+    const long wgs = (long)batch * ((N + 127) / 128), cus = device_cus() > 0 ? device_cus() : 256;
+    if (!lay.kmask && !lay.drop_thr && !lay.out_bf16 && N >= 128 && (tun.v[1] == 4 ||
+         (tun.v[1] == 0 && wgs <= (causal ? FWD_SPLITK_MAX_WGS_PER_CU_CAUSAL : FWD_SPLITK_MAX_WGS_PER_CU) * cus))) {
+      const int nqb = (N + 31) / 32;
+      FA_LAUNCH((fa::fwd_splitk_f32_kernel<D>), dim3((unsigned)(batch * nqb)), dim3(256), 0, st, (const float*)q, (const float*)k,
+                (const float*)v, out, l, m, N, nqb, batch, lay, causal, variant, tau);
+      FA_HIP_TRY(hipGetLastError());
+      return FA_OK;
+    }
+  }
   if constexpr (sizeof(T) == 2 && (D == 64 || D == 128)) {
     // FA-2 side output, bf16, d = 64 / 128, non-causal: slot-interleaved three-deep pipeline.  Under the causal mask the slot build
     // WITH masked period variants is 3.6 % slower than the phased kernel (128-query workgroups, per-wave tile skipping), which keeps

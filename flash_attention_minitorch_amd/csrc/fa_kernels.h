@@ -32,6 +32,7 @@
 #pragma once
 #include "fa_common.h"
 #include "fa_fwd.h"
+#include "fa_fwd_splitk_f32.h"
 #include "fa_bwd_dkdv.h"
 #include "fa_bwd_dq.h"
 #include "fa_bwd_onepass_f32.h"

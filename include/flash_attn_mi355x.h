@@ -128,7 +128,10 @@ int fa_mi355x_bwd_stages(const void* q, const void* k, const void* v, const floa
  *   opts[0]  dK/dV kernel: 3 = (d = 64) the phased kernel with the slot path on unmasked stages (what causal launches that do not
  *            fill the chip run anyway); 4 = the compiler-interleaved phased kernel (fp32 scaling: OPTS_EXACT_SCALE); 5 = at d = 64, causal,
  *            N % 256 == 0: the causal build of the continuous slot pipeline whatever the launch size
- *   opts[1]  forward kernel: 2 = phased (fp32 scaling), 3 = slot kernel also under the causal mask (whatever the launch size)
+ *   opts[1]  forward kernel: 2 = phased (fp32 scaling), 3 = slot kernel also under the causal mask (whatever the launch size);
+ *            fp32, d = 64: 4 = the split-key forward whatever the launch size (a workgroup = one 32-query block, its four waves a quarter
+ *            of the keys each, partial (O, l, m) combined through LDS: the default of launches that would leave most of the chip idle,
+ *            up to 128 workgroups of the phased kernel, 256 under the causal mask), 2 = never
  *   opts[2]  dQ kernel: 2 = phased with 32-key tiles (fp32 scaling), 3 = slot kernel also under the causal mask
  *   opts[3]  (diagnostic library only)
  *   opts[4]  1 = keep the separate preprocess kernel (default: the dQ launch preprocesses its own rows, writes the workspace and runs

@@ -280,6 +280,34 @@ def test_fp32_one_pass_backward_split_sweeps(dev, BH, N, causal):
         assert maxabs(to_np(a)[heads], ref[nm]) < TOL32, nm
 
 
+@pytest.mark.parametrize("BH,N", [(1, 128), (3, 129), (2, 200), (8, 1024), (5, 1000), (3, 1056), (7, 160)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp32_split_key_forward(dev, BH, N, causal):
+    """fp32, d = 64, launches that leave most of the chip idle: the default forward is fwd_splitk_f32_kernel (a workgroup = one 32-query
+    block, wave w the key tiles w, w + 4, ...; classic online softmax per wave as src/flash_attn_fw.cu:163-245, the four partial (O, l, m)
+    combined through LDS).  Against the fp64 oracle at the fp32 tolerance (O, L, and FA-1's m and l), both side-output conventions,
+    ragged N, waves without a tile (N = 128, 160) or without an admissible key under the causal mask; and against the phased forward."""
+    import torch
+    from flash_attention_minitorch_amd import _lib
+    assert _lib.plan(BH, N, 64, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, 0, None) == ["fwd_splitk_f32_kernel"]
+    assert _lib.plan(BH, N, 64, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, 0, (0, 2)) == ["fwd_kernel"]
+    assert _lib.plan(512, 1024, 64, causal, _lib.FA_VARIANT_FA2, _lib.FA_DTYPE_F32, 0, None) == ["fwd_kernel"]   # a launch that fills the chip
+    rng = np.random.default_rng(BH * 7919 + N)
+    arrs = [rand_u(rng, (BH, N, 64)) for _ in range(3)]
+    q, k, v = (torch.from_numpy(a).to("cuda") for a in arrs)
+    ref = oracle_heads(*arrs, None, causal, range(BH))
+    for variant in (_lib.FA_VARIANT_FA1, _lib.FA_VARIANT_FA2):
+        o, l, m = dev.flash_attn_fwd(q, k, v, causal, variant)
+        o2, _, _ = dev.flash_attn_fwd(q, k, v, causal, variant, opts=(0, 2))
+        assert maxabs(to_np(o), ref["o"]) < TOL32
+        assert float((o - o2).abs().max()) < 1e-5
+        if variant == _lib.FA_VARIANT_FA1:
+            assert maxabs(to_np(m), ref["m"]) < 1e-5 and maxabs(to_np(l), ref["l"]) < TOL32 * max(1.0, float(np.max(ref["l"])))
+            assert maxabs(to_np(m) + np.log(to_np(l)), ref["L"]) < TOL32
+        else:
+            assert maxabs(to_np(l), ref["L"]) < TOL32
+
+
 # ---------------------------------------------------------------- bf16 device path: metric shape M and configs[3]
 def _bf16_case(dev, B, H, N, d, causal, heads, seed):
     import torch
